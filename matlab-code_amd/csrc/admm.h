@@ -1,0 +1,62 @@
+// ADMM inner-loop kernels and the proximal operator catalogue
+// (functions/cmtf_fun_AOADMM.m:591-623,1420-1429 ; functions/constraints_to_prox.m:13-91).
+#pragma once
+#include "common.h"
+#include "small.h"
+
+namespace aoadmm {
+
+struct ProxSpec {
+  int type = AOADMM_C_NONE;
+  double p0 = 0.0, p1 = 0.0;       // constraint parameters (eta | l,u | nn)
+  const double* Lmat = nullptr;    // device, AOADMM_C_QUADRATIC only
+};
+
+bool prox_is_fusable(int type);     // element-wise or row-wise: folded into the primal kernel
+size_t prox_ws_bytes(int type, int64_t rows, int R);
+
+// Z_out = prox(V, rho) for any catalogue entry; rho read from device memory.
+void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, int64_t ldz,
+                int64_t rows, int R, const double* rho_dev, double rho_mul, double* ws,
+                const AdmmCtl* ctl, hipStream_t s);
+
+// One iteration of ADMM_constrained_only (:608-620) for a CP mode.
+//   fusable prox : fac, Z, mu updated in one row-parallel kernel;
+//   other prox   : primal kernel -> column/matrix prox kernel -> dual kernel.
+// `part` holds >= admm_partials(rows) * 4 doubles; `V`,`Znew` are rows*R scratch (non-fusable only).
+struct AdmmMode {
+  const double* A;      // MTTKRP (+bsum term)            rows x R
+  const double* L;      // chol factor                     R x R
+  const double* rho;    // device scalar
+  double *fac, *Z, *mu; // rows x R each
+  int64_t rows;
+  int R;
+  ProxSpec prox;
+};
+int admm_partials(int64_t rows);
+void admm_constrained_iteration(const AdmmMode& m, double* part, double* V, double* Znew, double* prox_ws,
+                                AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du,
+                                hipStream_t s);
+
+// generic pieces for the coupled / PARAFAC2 loops -------------------------------
+// (Z,mu) <- update_constraint (:1420-1429): Zold kept in `Zold`; slots[0..3] receive
+// ||fac-Z||^2, ||fac||^2, ||mu||^2, ||Z-Zold||^2
+void constraint_update(const ProxSpec& ps, const double* fac, double* Z, double* mu, double* Zold,
+                       double* V, int64_t rows, int R, const double* rho_dev, double rho_mul,
+                       double* prox_ws, double* slots, double* red_ws, const AdmmCtl* ctl,
+                       hipStream_t s);
+
+// residual bookkeeping at the end of a generic inner iteration; per participating mode a block of
+// 8 slots: [0]=||fac-Z||^2 [1]=||fac||^2 [2]=||mu||^2 [3]=||Z-Zold||^2
+//          [4]=||fac-T(Delta)||^2 [5]=||mu_Delta||^2 [6]=||T(Delta-Delta_old)||^2 [7]=flags as double
+struct FinalizeArgs {
+  const double* slots[8];
+  int constrained[8];
+  int coupled[8];
+  int nmodes;
+  int max_inner;
+  double tol_pr_coupl, tol_pr_constr, tol_du_coupl, tol_du_constr;
+};
+void admm_finalize_generic(const FinalizeArgs& fa, AdmmCtl* ctl, hipStream_t s);
+
+}  // namespace aoadmm

@@ -1,0 +1,848 @@
+// ADMM inner loop + proximal operators on gfx950.
+// Reference: functions/cmtf_fun_AOADMM.m:591-623 (ADMM_constrained_only), :1420-1429
+// (update_constraint), :1079-1096 (eval_res_ADMM_constr); functions/constraints_to_prox.m.
+#include "admm.h"
+
+namespace aoadmm {
+
+#define CTL_GUARD(ctl) \
+  if ((ctl) != nullptr && (ctl)->active == 0) return;
+
+// ===========================================================================
+// element-wise / row-wise prox (fusable)
+// ===========================================================================
+bool prox_is_fusable(int t) {
+  return t == AOADMM_C_NONNEG || t == AOADMM_C_BOX || t == AOADMM_C_L1_REG || t == AOADMM_C_L0_REG ||
+         t == AOADMM_C_RIDGE || t == AOADMM_C_SIMPLEX_ROW;
+}
+
+__device__ __forceinline__ double prox_elem(int type, double v, double p0, double p1, double rho) {
+  switch (type) {
+    case AOADMM_C_NONNEG: return fmax(v, 0.0);                          // project_box(x,0,inf)  (:14)
+    case AOADMM_C_BOX: return fmin(fmax(v, p0), p1);                    // (:18)
+    case AOADMM_C_L1_REG: {                                             // prox_abs(x,eta/rho) (:48)
+      const double g = p0 / rho;
+      const double m = fabs(v) - g;
+      return m > 0.0 ? copysign(m, v) : 0.0;
+    }
+    case AOADMM_C_L0_REG: {                                             // prox_zero (:52)
+      const double g = p0 / rho;
+      return v * v > 2.0 * g ? v : 0.0;
+    }
+    case AOADMM_C_RIDGE: return 1.0 / (2.0 * (p0 / rho) + 1.0) * v;     // (:60)
+    default: return v;
+  }
+}
+
+// exact projection of v[0..R) onto {x >= 0, sum x = eta}: fixed point of
+// tau <- (sum_{v_i > tau} v_i - eta) / #{v_i > tau}  (nested active sets, finite termination)
+template <int RMAX>
+__device__ __forceinline__ void simplex_regs(double (&v)[RMAX], int R, double eta) {
+  double tau = -INFINITY;
+  int cnt_prev = -1;
+  for (int it = 0; it <= RMAX; ++it) {
+    double sum = 0.0;
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (r < R && v[r] > tau) { sum += v[r]; ++cnt; }
+    if (cnt == cnt_prev || cnt == 0) break;
+    cnt_prev = cnt;
+    tau = (sum - eta) / cnt;
+  }
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r)
+    if (r < R) v[r] = fmax(v[r] - tau, 0.0);
+}
+
+// ===========================================================================
+// fused primal (+ dual) step, thread per row
+// ===========================================================================
+template <int RMAX>
+__device__ __forceinline__ void row_solve_regs2(double (&x)[RMAX], const double* Lsh, int R) {
+#pragma unroll
+  for (int j = 0; j < RMAX; ++j) {
+    if (j < R) {
+      double v = x[j];
+#pragma unroll
+      for (int q = 0; q < j; ++q) v -= Lsh[j + R * q] * x[q];
+      x[j] = v / Lsh[j + R * j];
+    }
+  }
+#pragma unroll
+  for (int j = RMAX - 1; j >= 0; --j) {
+    if (j < R) {
+      double v = x[j];
+#pragma unroll
+      for (int q = j + 1; q < RMAX; ++q)
+        if (q < R) v -= Lsh[q + R * j] * x[q];
+      x[j] = v / Lsh[j + R * j];
+    }
+  }
+}
+
+struct FusedArgs {
+  const double *A, *L, *rho;
+  double *fac, *Z, *mu, *V, *part;
+  int64_t rows;
+  int R, fused, ptype;
+  double p0, p1;
+};
+
+static constexpr int kRowThreads = 128;
+
+template <int RMAX>
+__global__ __launch_bounds__(kRowThreads) void admm_row_k(FusedArgs a, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  extern __shared__ double Lsh[];
+  __shared__ double red[4][kRowThreads / 64];
+  const int R = a.R;
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) Lsh[e] = a.L[e];
+  __syncthreads();
+  const double rho = a.rho[0];
+  const double rh = rho / 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+  if (i < a.rows) {
+    double x[RMAX], mu[RMAX], zo[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      if (r < R) {
+        const int64_t o = i + a.rows * r;
+        zo[r] = a.Z[o];
+        mu[r] = a.mu[o];
+        x[r] = a.A[o] + rh * (zo[r] - mu[r]);       // A_inner = A + rho/2*(Z - mu)   (:608)
+      } else {
+        x[r] = 0; mu[r] = 0; zo[r] = 0;
+      }
+    }
+    row_solve_regs2<RMAX>(x, Lsh, R);               // fac = (A_inner/L')/L            (:609)
+    if (a.fused) {
+      double z[RMAX];
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) z[r] = x[r] + mu[r];
+      if (a.ptype == AOADMM_C_SIMPLEX_ROW) {
+        simplex_regs<RMAX>(z, R, a.p0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) z[r] = prox_elem(a.ptype, z[r], a.p0, a.p1, rho);
+      }
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        if (r < R) {
+          const int64_t o = i + a.rows * r;
+          const double mn = mu[r] + x[r] - z[r];     // mu = mu + fac - Z              (:1428)
+          a.fac[o] = x[r];
+          a.Z[o] = z[r];
+          a.mu[o] = mn;
+          const double d = x[r] - z[r];
+          s1 += d * d;
+          s2 += x[r] * x[r];
+          s3 += mn * mn;
+          const double e = z[r] - zo[r];
+          s4 += e * e;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        if (r < R) {
+          const int64_t o = i + a.rows * r;
+          a.fac[o] = x[r];
+          a.V[o] = x[r] + mu[r];
+        }
+      }
+    }
+  }
+  if (a.fused) {
+    // deterministic block reduction: wave shuffle tree then fixed-order sum over waves
+    for (int off = 32; off > 0; off >>= 1) {
+      s1 += __shfl_down(s1, off);
+      s2 += __shfl_down(s2, off);
+      s3 += __shfl_down(s3, off);
+      s4 += __shfl_down(s4, off);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = s1; red[1][w] = s2; red[2][w] = s3; red[3][w] = s4; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double t = 0;
+      for (int k = 0; k < kRowThreads / 64; ++k) t += red[threadIdx.x][k];
+      a.part[(int64_t)blockIdx.x * 4 + threadIdx.x] = t;
+    }
+  }
+}
+
+int admm_partials(int64_t rows) {
+  const int64_t a = cdiv(rows, kRowThreads);
+  return (int)(a > 64 ? a : 64);
+}
+
+// element-wise dual update after a column-wise prox: mu += fac - Znew ; Z <- Znew ; partial norms
+__global__ void dual_update_k(const double* fac, double* Z, double* mu, const double* Znew, int64_t n,
+                              double* part, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  __shared__ double red[4][4];
+  double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double x = fac[i], z = Znew[i], zo = Z[i];
+    const double mn = mu[i] + x - z;
+    mu[i] = mn;
+    Z[i] = z;
+    const double d = x - z, e = z - zo;
+    s1 += d * d; s2 += x * x; s3 += mn * mn; s4 += e * e;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off);
+    s3 += __shfl_down(s3, off); s4 += __shfl_down(s4, off);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = s1; red[1][w] = s2; red[2][w] = s3; red[3][w] = s4; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[threadIdx.x][k];
+    part[(int64_t)blockIdx.x * 4 + threadIdx.x] = t;
+  }
+}
+
+// eval_res_ADMM_constr (:1079-1096) + loop condition (:600) for one mode
+__global__ void admm_finalize_k(const double* part, int nblocks, AdmmCtl* ctl, int max_inner, double tol_pr,
+                                double tol_du, double* slots) {
+  if (ctl->active == 0) return;
+  __shared__ double tot[4];
+  if (threadIdx.x < 4) {
+    double t = 0;
+    for (int b = 0; b < nblocks; ++b) t += part[(int64_t)b * 4 + threadIdx.x];
+    tot[threadIdx.x] = t;
+    if (slots) slots[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double pr = sqrt(tot[0]) / sqrt(tot[1]);
+    const double sc = sqrt(tot[2]);
+    const double du = sc > 0 ? sqrt(tot[3]) / sc : sqrt(tot[3]);
+    ctl->res[1] = pr;
+    ctl->res[3] = du;
+    const int it = ctl->iters + 1;
+    ctl->iters = it;
+    ctl->active = (it < max_inner && (pr > tol_pr || du > tol_du)) ? 1 : 0;
+  }
+}
+
+// ===========================================================================
+// column-wise prox kernels: one block per column
+// ===========================================================================
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  // fixed-order tree over blockDim.x (power of two <= 256)
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int st = blockDim.x >> 1; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+struct ColArgs {
+  const double* V;
+  double* Z;
+  int64_t ldv, ldz, rows;
+  int R, type;
+  double p0, p1;
+  const double* rho;
+  double rho_mul;
+  double* ws;
+};
+
+// l2-ball family, l2 regularisation, non-negative sphere (:37,:40,:43,:56)
+__global__ void prox_colnorm_k(ColArgs a, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  __shared__ double sh[256];
+  __shared__ double shv[256];
+  __shared__ int shi[256];
+  const int r = blockIdx.x;
+  const double* v = a.V + a.ldv * r;
+  double* z = a.Z + a.ldz * r;
+  const bool clamp = a.type == AOADMM_C_NONNEG_L2_BALL || a.type == AOADMM_C_NONNEG_L2_SPHERE;
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < a.rows; i += blockDim.x) {
+    double y = v[i];
+    if (clamp) y = fmax(y, 0.0);
+    acc += y * y;
+  }
+  const double nrm = sqrt(block_sum(acc, sh));
+  if (a.type == AOADMM_C_NONNEG_L2_SPHERE) {
+    if (nrm == 0.0) {
+      // [~,maxcoord] = max(X(:,r)) : first maximum (prox_normalized_nonneg.m:6-7)
+      double bv = -INFINITY;
+      int64_t bi = 0;
+      for (int64_t i = threadIdx.x; i < a.rows; i += blockDim.x)
+        if (v[i] > bv) { bv = v[i]; bi = i; }
+      shv[threadIdx.x] = bv;
+      shi[threadIdx.x] = (int)bi;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double best = shv[0];
+        int64_t besti = shi[0];
+        for (int t = 1; t < (int)blockDim.x; ++t)
+          if (shv[t] > best || (shv[t] == best && shi[t] < besti)) { best = shv[t]; besti = shi[t]; }
+        shi[0] = (int)besti;
+      }
+      __syncthreads();
+      const int64_t arg = shi[0];
+      for (int64_t i = threadIdx.x; i < a.rows; i += blockDim.x) z[i] = (i == arg) ? 1.0 : 0.0;
+    } else {
+      for (int64_t i = threadIdx.x; i < a.rows; i += blockDim.x) z[i] = fmax(v[i], 0.0) / nrm;
+    }
+    return;
+  }
+  double scale;
+  if (a.type == AOADMM_C_L2_REG) {
+    const double g = a.p0 / (a.rho[0] * a.rho_mul);
+    scale = nrm > g ? 1.0 - g / nrm : 0.0;
+  } else {
+    scale = nrm > a.p0 ? a.p0 / nrm : 1.0;
+  }
+  for (int64_t i = threadIdx.x; i < a.rows; i += blockDim.x) {
+    double y = v[i];
+    if (clamp) y = fmax(y, 0.0);
+    z[i] = y * scale;
+  }
+}
+
+// simplex column-wise / l1-ball (:21,:34): parallel fixed-point for the exact threshold
+__global__ void prox_simplex_col_k(ColArgs a, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  __shared__ double sh[256];
+  const int r = blockIdx.x;
+  const double* v = a.V + a.ldv * r;
+  double* z = a.Z + a.ldz * r;
+  const bool l1 = a.type == AOADMM_C_L1_BALL;
+  const double eta = a.p0;
+  if (l1) {
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < a.rows; i += blockDim.x) acc += fabs(v[i]);
+    const double n1 = block_sum(acc, sh);
+    if (!(n1 > eta)) {
+      for (int64_t i = threadIdx.x; i < a.rows; i += blockDim.x) z[i] = v[i];
+      return;
+    }
+  }
+  double tau = -INFINITY;
+  double cnt_prev = -1.0;
+  for (int64_t it = 0; it <= a.rows; ++it) {
+    double s = 0.0, c = 0.0;
+    for (int64_t i = threadIdx.x; i < a.rows; i += blockDim.x) {
+      const double y = l1 ? fabs(v[i]) : v[i];
+      if (y > tau) { s += y; c += 1.0; }
+    }
+    const double S = block_sum(s, sh);
+    const double Cn = block_sum(c, sh);
+    if (Cn == cnt_prev || Cn == 0.0) break;
+    cnt_prev = Cn;
+    tau = (S - eta) / Cn;
+  }
+  for (int64_t i = threadIdx.x; i < a.rows; i += blockDim.x) {
+    if (l1) {
+      const double w = fmax(fabs(v[i]) - tau, 0.0);
+      z[i] = v[i] > 0 ? w : (v[i] < 0 ? -w : 0.0);
+    } else {
+      z[i] = fmax(v[i] - tau, 0.0);
+    }
+  }
+}
+
+// ---- sequential column algorithms (one thread per task, data in LDS or L2-resident scratch)
+
+// Exact 1-D TV prox: L. Condat, IEEE SPL 20(11) 2013 (restated; TV_Condat_v2 at prox_TV.m:7
+// returns the same unique minimiser).
+__device__ void tv1d_condat_dev(const double* y, double* x, int64_t n, double lam) {
+  if (n <= 0) return;
+  if (!(lam > 0.0)) {
+    for (int64_t i = 0; i < n; ++i) x[i] = y[i];
+    return;
+  }
+  int64_t k = 0, k0 = 0, km = 0, kp = 0;
+  double vmin = y[0] - lam, vmax = y[0] + lam, umin = lam, umax = -lam;
+  for (;;) {
+    if (k == n - 1) {
+      if (umin < 0.0) {
+        do { x[k0++] = vmin; } while (k0 <= km);
+        k = km = kp = k0;
+        vmin = y[k];
+        umin = lam;
+        umax = vmin + umin - vmax;
+      } else if (umax > 0.0) {
+        do { x[k0++] = vmax; } while (k0 <= kp);
+        k = km = kp = k0;
+        vmax = y[k];
+        umax = -lam;
+        umin = vmax + umax - vmin;
+      } else {
+        vmin += umin / (double)(k - k0 + 1);
+        do { x[k0++] = vmin; } while (k0 <= k);
+        return;
+      }
+    } else {
+      umin += y[k + 1] - vmin;
+      if (umin < -lam) {
+        do { x[k0++] = vmin; } while (k0 <= km);
+        k = km = kp = k0;
+        vmin = y[k];
+        vmax = vmin + 2.0 * lam;
+        umin = lam;
+        umax = -lam;
+      } else {
+        umax += y[k + 1] - vmax;
+        if (umax > lam) {
+          do { x[k0++] = vmax; } while (k0 <= kp);
+          k = km = kp = k0;
+          vmax = y[k];
+          vmin = vmax - 2.0 * lam;
+          umin = lam;
+          umax = -lam;
+        } else {
+          ++k;
+          if (umin >= lam) {
+            km = k;
+            vmin += (umin - lam) / (double)(km - k0 + 1);
+            umin = lam;
+          }
+          if (umax <= -lam) {
+            kp = k;
+            vmax += (umax + lam) / (double)(kp - k0 + 1);
+            umax = -lam;
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void prox_tv_k(ColArgs a, int use_lds, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  extern __shared__ double dyn[];
+  const int r = blockIdx.x;
+  const double* v = a.V + a.ldv * r;
+  double* z = a.Z + a.ldz * r;
+  const double lam = a.p0 / (a.rho[0] * a.rho_mul);     // prox_TV(x, eta/rho)  (:80)
+  if (use_lds) {
+    double* y = dyn;
+    double* x = dyn + a.rows;
+    for (int64_t i = threadIdx.x; i < a.rows; i += blockDim.x) y[i] = v[i];
+    __syncthreads();
+    if (threadIdx.x == 0) tv1d_condat_dev(y, x, a.rows, lam);
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < a.rows; i += blockDim.x) z[i] = x[i];
+  } else {
+    if (threadIdx.x == 0) tv1d_condat_dev(v, z, a.rows, lam);
+  }
+}
+
+// isotonic regression (PAVA), non-decreasing; `sign` = -1 gives -project_monotone(-x) (:26,:28)
+__global__ void prox_monotone_k(ColArgs a, double sign, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  if (threadIdx.x != 0) return;
+  const int r = blockIdx.x;
+  const int64_t n = a.rows;
+  const double* v = a.V + a.ldv * r;
+  double* z = a.Z + a.ldz * r;
+  double* val = a.ws + (int64_t)r * 3 * n;
+  double* wt = val + n;
+  double* len = wt + n;
+  int64_t nb = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    val[nb] = sign * v[i];
+    wt[nb] = 1.0;
+    len[nb] = 1.0;
+    ++nb;
+    while (nb > 1 && val[nb - 2] > val[nb - 1]) {
+      const double w = wt[nb - 2] + wt[nb - 1];
+      val[nb - 2] = (val[nb - 2] * wt[nb - 2] + val[nb - 1] * wt[nb - 1]) / w;
+      wt[nb - 2] = w;
+      len[nb - 2] += len[nb - 1];
+      --nb;
+    }
+  }
+  int64_t o = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    const int64_t L = (int64_t)len[b];
+    for (int64_t t = 0; t < L; ++t) z[o++] = sign * val[b];
+  }
+}
+
+// unimodal regression: functions/project_unimodal_vector.m (Stout 2008).  Two threads run the
+// prefix isotonic regressions (:11,:12); thread 0 picks the split (:21-32) and rebuilds (:34-41).
+// All arrays keep MATLAB's 1-based indexing (slot 0 unused).
+__device__ void prefix_isotonic_dev(const double* y, int64_t n, bool flip, bool nonneg, double* sumwy,
+                                    double* sumwy2, double* sumw, double* level, double* idxr,
+                                    double* err, double* cums, double* thr) {
+  // y accessed as y(i) = flip ? y[n-i] : y[i-1], i = 1..n
+  sumwy[1] = 0; sumwy2[1] = 0; sumw[1] = 0;
+  level[1] = -INFINITY; idxr[1] = 0; err[1] = 0;
+  double run = 0.0;
+  cums[1] = 0.0;
+  for (int64_t i = 2; i <= n + 1; ++i) {
+    const double yi = flip ? y[n - (i - 1)] : y[i - 2];
+    sumwy[i] = yi; sumwy2[i] = yi * yi; sumw[i] = 1.0;
+    run += yi * yi;
+    cums[i] = run;                                   // cumsum(sumwy2) (:56)
+    thr[i] = 0.0;
+  }
+  for (int64_t i = 2; i <= n + 1; ++i) {
+    level[i] = sumwy[i];                             // y(i-1) (:61)
+    int64_t ir = i;                                  // :62
+    while (level[i] <= level[ir - 1]) {              // :63
+      const int64_t mg = ir - 1;
+      sumwy[i] += sumwy[mg];                         // :83-86
+      sumwy2[i] += sumwy2[mg];
+      sumw[i] += sumw[mg];
+      level[i] = sumwy[i] / sumw[i];
+      ir = (int64_t)idxr[ir - 1];                    // :65
+    }
+    idxr[i] = (double)ir;
+    const double levelerror = sumwy2[i] - (sumwy[i] * sumwy[i] / sumw[i]);   // :67
+    if (nonneg && level[i] < 0) {
+      thr[i] = 1.0;
+      err[i] = cums[i - 1];                          // :70
+    } else {
+      err[i] = levelerror + err[ir - 1];             // :72
+    }
+  }
+  if (nonneg)
+    for (int64_t i = 2; i <= n + 1; ++i)
+      if (thr[i] != 0.0) level[i] = 0.0;             // :76
+}
+
+__global__ void prox_unimodal_k(ColArgs a, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  const int r = blockIdx.x;
+  const int64_t n = a.rows;
+  const double* v = a.V + a.ldv * r;
+  double* z = a.Z + a.ldz * r;
+  const int64_t st = n + 2;
+  double* base = a.ws + (int64_t)r * 16 * st;
+  const bool nonneg = a.p0 != 0.0;
+  if (threadIdx.x < 2) {
+    double* b = base + (int64_t)threadIdx.x * 8 * st;
+    prefix_isotonic_dev(v, n, threadIdx.x == 1, nonneg, b, b + st, b + 2 * st, b + 3 * st, b + 4 * st,
+                        b + 5 * st, b + 6 * st, b + 7 * st);
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double* lvlL = base + 3 * st;  const double* idxL = base + 4 * st;  const double* errL = base + 5 * st;
+  const double* lvlR = base + 8 * st + 3 * st;  const double* idxR = base + 8 * st + 4 * st;
+  const double* errR = base + 8 * st + 5 * st;
+  // returned arrays of the reference are the slots 2..n+1 -> element t (1-based) is slot t+1;
+  // iso(:,2) = index_range(2:end)-1
+  double best = errR[n + 1];                                    // error_right(end)  (:22)
+  int64_t best_idx = 1;
+  for (int64_t i = 2; i <= n; ++i) {                            // :24-30
+    const double e = errL[i + 1] + errR[(n - (i - 1)) + 1];
+    if (e < best) { best = e; best_idx = i; }
+  }
+  // left part: positions 1..best_idx  (:15, :34-41)
+  {
+    int64_t idx = best_idx;
+    while (idx >= 1) {
+      const int64_t lo = (int64_t)idxL[idx + 1] - 1;
+      for (int64_t t = lo; t <= idx; ++t) z[t - 1] = lvlL[idx + 1];
+      idx = lo - 1;
+    }
+  }
+  // right part: mode_idx = n - best_idx on the flipped vector, written back flipped (:16,:18)
+  {
+    const int64_t mlen = n - best_idx;
+    int64_t idx = mlen;
+    while (idx >= 1) {
+      const int64_t lo = (int64_t)idxR[idx + 1] - 1;
+      for (int64_t t = lo; t <= idx; ++t) z[n - t] = lvlR[idx + 1];   // flip: element t of the flipped part
+      idx = lo - 1;
+    }
+  }
+}
+
+// GL smoothness: (2*eta/rho*L + I) \ x with the path-graph Laplacian (:68-76): Thomas algorithm
+__global__ void prox_gl_k(ColArgs a, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  if (threadIdx.x != 0) return;
+  const int r = blockIdx.x;
+  const int64_t n = a.rows;
+  const double* v = a.V + a.ldv * r;
+  double* z = a.Z + a.ldz * r;
+  double* cp = a.ws + (int64_t)r * n;
+  const double s2 = 2.0 * (a.p0 / (a.rho[0] * a.rho_mul));
+  if (n == 1) { z[0] = v[0] / (s2 * 1.0 + 1.0); return; }
+  const double off = -s2;
+  double diag = s2 * 1.0 + 1.0;
+  cp[0] = off / diag;
+  z[0] = v[0] / diag;
+  for (int64_t i = 1; i < n; ++i) {
+    const double d = ((i == n - 1) ? s2 * 1.0 : s2 * 2.0) + 1.0;
+    const double m = d - off * cp[i - 1];
+    cp[i] = off / m;
+    z[i] = (v[i] - off * z[i - 1]) / m;
+  }
+  for (int64_t i = n - 2; i >= 0; --i) z[i] -= cp[i] * z[i + 1];
+}
+
+// orthonormal columns: U*V' of the thin SVD (project_ortho.m:3-4) by one-sided (Hestenes) Jacobi.
+// W (rows x R) is worked on in place in Zout; J (R x R) accumulates the rotations in LDS.
+__global__ void prox_ortho_k(ColArgs a, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  extern __shared__ double dyn[];
+  __shared__ double sh[256];
+  __shared__ double cs[2];
+  __shared__ int rotated;
+  const int R = a.R;
+  double* J = dyn;          // R*R
+  const int64_t n = a.rows;
+  double* W = a.ws;         // rows x R contiguous copy
+  for (int64_t e = threadIdx.x; e < n * R; e += blockDim.x) W[e] = a.V[(e % n) + a.ldv * (e / n)];
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) J[e] = (e % R == e / R) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    if (threadIdx.x == 0) rotated = 0;
+    __syncthreads();
+    for (int p = 0; p < R - 1; ++p) {
+      for (int q = p + 1; q < R; ++q) {
+        double* wp = W + n * p;
+        double* wq = W + n * q;
+        double al = 0, be = 0, ga = 0;
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+          al += wp[i] * wp[i]; be += wq[i] * wq[i]; ga += wp[i] * wq[i];
+        }
+        al = block_sum(al, sh); be = block_sum(be, sh); ga = block_sum(ga, sh);
+        if (threadIdx.x == 0) {
+          double c = 1.0, s = 0.0;
+          if (fabs(ga) > 1e-15 * sqrt(al * be) && ga != 0.0) {
+            const double zeta = (be - al) / (2.0 * ga);
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            c = 1.0 / sqrt(1.0 + t * t);
+            s = c * t;
+            rotated = 1;
+          }
+          cs[0] = c; cs[1] = s;
+        }
+        __syncthreads();
+        const double c = cs[0], s = cs[1];
+        if (s != 0.0) {
+          for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const double x = wp[i], y = wq[i];
+            wp[i] = c * x - s * y;
+            wq[i] = s * x + c * y;
+          }
+          for (int i = threadIdx.x; i < R; i += blockDim.x) {
+            const double x = J[i + R * p], y = J[i + R * q];
+            J[i + R * p] = c * x - s * y;
+            J[i + R * q] = s * x + c * y;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (!rotated) break;
+    __syncthreads();
+  }
+  // normalise columns: U = W * diag(1/sigma)
+  for (int p = 0; p < R; ++p) {
+    double* wp = W + n * p;
+    double al = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) al += wp[i] * wp[i];
+    al = block_sum(al, sh);
+    const double sg = sqrt(al);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) wp[i] = sg > 0 ? wp[i] / sg : 0.0;
+    __syncthreads();
+  }
+  // Z = U * J'
+  for (int64_t e = threadIdx.x; e < n * R; e += blockDim.x) {
+    const int64_t i = e % n;
+    const int r = (int)(e / n);
+    double acc = 0.0;
+    for (int k = 0; k < R; ++k) acc += W[i + n * k] * J[r + R * k];
+    a.Z[i + a.ldz * r] = acc;
+  }
+}
+
+// stand-alone element-wise / row-wise prox (op-level entry and the generic loops)
+template <int RMAX>
+__global__ void prox_rows_k(ColArgs a, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.rows) return;
+  const double rho = a.rho[0] * a.rho_mul;
+  double z[RMAX];
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) z[r] = r < a.R ? a.V[i + a.ldv * r] : 0.0;
+  if (a.type == AOADMM_C_SIMPLEX_ROW) {
+    simplex_regs<RMAX>(z, a.R, a.p0);
+  } else {
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) z[r] = prox_elem(a.type, z[r], a.p0, a.p1, rho);
+  }
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r)
+    if (r < a.R) a.Z[i + a.ldz * r] = z[r];
+}
+
+static constexpr int64_t kTvLdsRows = 8192;
+
+size_t prox_ws_bytes(int type, int64_t rows, int R) {
+  switch (type) {
+    case AOADMM_C_NONDECREASING:
+    case AOADMM_C_NONINCREASING: return (size_t)R * 3 * rows * sizeof(double);
+    case AOADMM_C_UNIMODAL: return (size_t)R * 16 * (rows + 2) * sizeof(double);
+    case AOADMM_C_GL_SMOOTH: return (size_t)R * rows * sizeof(double);
+    case AOADMM_C_ORTHONORMAL: return (size_t)R * rows * sizeof(double);
+    default: return 16;
+  }
+}
+
+void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, int64_t ldz,
+                int64_t rows, int R, const double* rho_dev, double rho_mul, double* ws,
+                const AdmmCtl* ctl, hipStream_t s) {
+  ColArgs a;
+  a.V = V; a.Z = Zout; a.ldv = ldv; a.ldz = ldz; a.rows = rows; a.R = R; a.type = ps.type;
+  a.p0 = ps.p0; a.p1 = ps.p1; a.rho = rho_dev; a.rho_mul = rho_mul; a.ws = ws;
+  if (rows <= 0 || R <= 0) return;
+  switch (ps.type) {
+    case AOADMM_C_NONNEG: case AOADMM_C_BOX: case AOADMM_C_L1_REG: case AOADMM_C_L0_REG:
+    case AOADMM_C_RIDGE: case AOADMM_C_SIMPLEX_ROW: {
+      const unsigned blocks = (unsigned)cdiv(rows, 128);
+      if (R <= 8) prox_rows_k<8><<<blocks, 128, 0, s>>>(a, ctl);
+      else if (R <= 16) prox_rows_k<16><<<blocks, 128, 0, s>>>(a, ctl);
+      else if (R <= 32) prox_rows_k<32><<<blocks, 128, 0, s>>>(a, ctl);
+      else prox_rows_k<64><<<blocks, 128, 0, s>>>(a, ctl);
+      break;
+    }
+    case AOADMM_C_L2_BALL: case AOADMM_C_NONNEG_L2_BALL: case AOADMM_C_NONNEG_L2_SPHERE: case AOADMM_C_L2_REG:
+      prox_colnorm_k<<<R, 256, 0, s>>>(a, ctl);
+      break;
+    case AOADMM_C_SIMPLEX_COL: case AOADMM_C_L1_BALL:
+      prox_simplex_col_k<<<R, 256, 0, s>>>(a, ctl);
+      break;
+    case AOADMM_C_TV: {
+      const int use_lds = rows <= kTvLdsRows;
+      const size_t sh = use_lds ? (size_t)2 * rows * sizeof(double) : 0;
+      if (sh > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+          AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prox_tv_k),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTvLdsRows * sizeof(double))));
+          attr_set = true;
+        }
+      }
+      prox_tv_k<<<R, 64, sh, s>>>(a, use_lds, ctl);
+      break;
+    }
+    case AOADMM_C_NONDECREASING: prox_monotone_k<<<R, 64, 0, s>>>(a, 1.0, ctl); break;
+    case AOADMM_C_NONINCREASING: prox_monotone_k<<<R, 64, 0, s>>>(a, -1.0, ctl); break;
+    case AOADMM_C_UNIMODAL: prox_unimodal_k<<<R, 64, 0, s>>>(a, ctl); break;
+    case AOADMM_C_GL_SMOOTH: prox_gl_k<<<R, 64, 0, s>>>(a, ctl); break;
+    case AOADMM_C_ORTHONORMAL: prox_ortho_k<<<1, 256, (size_t)R * R * sizeof(double), s>>>(a, ctl); break;
+    default:
+      throw Error(AOADMM_ERR_UNSUPPORTED, fmt("constraint id %d has no device prox (route to the MATLAB path)", ps.type));
+  }
+  AO_KERNEL_CHECK();
+}
+
+// ===========================================================================
+// host-side composition
+// ===========================================================================
+void admm_constrained_iteration(const AdmmMode& m, double* part, double* V, double* Znew, double* prox_ws,
+                                AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du,
+                                hipStream_t s) {
+  FusedArgs a;
+  a.A = m.A; a.L = m.L; a.rho = m.rho; a.fac = m.fac; a.Z = m.Z; a.mu = m.mu; a.V = V; a.part = part;
+  a.rows = m.rows; a.R = m.R; a.ptype = m.prox.type; a.p0 = m.prox.p0; a.p1 = m.prox.p1;
+  a.fused = prox_is_fusable(m.prox.type) ? 1 : 0;
+  const unsigned blocks = (unsigned)cdiv(m.rows, kRowThreads);
+  const size_t sh = (size_t)m.R * m.R * sizeof(double);
+  if (m.R <= 8) admm_row_k<8><<<blocks, kRowThreads, sh, s>>>(a, ctl);
+  else if (m.R <= 16) admm_row_k<16><<<blocks, kRowThreads, sh, s>>>(a, ctl);
+  else if (m.R <= 32) admm_row_k<32><<<blocks, kRowThreads, sh, s>>>(a, ctl);
+  else admm_row_k<64><<<blocks, kRowThreads, sh, s>>>(a, ctl);
+  AO_KERNEL_CHECK();
+  int nparts = (int)blocks;
+  if (!a.fused) {
+    prox_apply(m.prox, V, m.rows, Znew, m.rows, m.rows, m.R, m.rho, 1.0, prox_ws, ctl, s);
+    int64_t n = m.rows * m.R;
+    int64_t nb = cdiv(n, 1024);
+    if (nb > 64) nb = 64;
+    dual_update_k<<<(unsigned)nb, 256, 0, s>>>(m.fac, m.Z, m.mu, Znew, n, part, ctl);
+    AO_KERNEL_CHECK();
+    nparts = (int)nb;
+  }
+  admm_finalize_k<<<1, 64, 0, s>>>(part, nparts, ctl, max_inner, tol_pr, tol_du, nullptr);
+  AO_KERNEL_CHECK();
+}
+
+__global__ void copy_add_k(double* V, double* Zold, const double* fac, const double* Z, const double* mu, int64_t n,
+                           const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    V[i] = fac[i] + mu[i];
+    Zold[i] = Z[i];
+  }
+}
+__global__ void dual_only_k(const double* fac, const double* Z, double* mu, int64_t n, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    mu[i] = mu[i] + fac[i] - Z[i];
+}
+
+void constraint_update(const ProxSpec& ps, const double* fac, double* Z, double* mu, double* Zold,
+                       double* V, int64_t rows, int R, const double* rho_dev, double rho_mul,
+                       double* prox_ws, double* slots, double* red_ws, const AdmmCtl* ctl,
+                       hipStream_t s) {
+  const int64_t n = rows * R;
+  int64_t nb = cdiv(n, 256);
+  if (nb > 1024) nb = 1024;
+  copy_add_k<<<(unsigned)nb, 256, 0, s>>>(V, Zold, fac, Z, mu, n, ctl);
+  AO_KERNEL_CHECK();
+  prox_apply(ps, V, rows, Z, rows, rows, R, rho_dev, rho_mul, prox_ws, ctl, s);   // Z = prox(fac+mu, rho)
+  dual_only_k<<<(unsigned)nb, 256, 0, s>>>(fac, Z, mu, n, ctl);                  // mu += fac - Z
+  AO_KERNEL_CHECK();
+  sumsq_diff(slots + 0, fac, Z, n, red_ws, ctl, s);
+  sumsq_diff(slots + 1, fac, nullptr, n, red_ws, ctl, s);
+  sumsq_diff(slots + 2, mu, nullptr, n, red_ws, ctl, s);
+  sumsq_diff(slots + 3, Z, Zold, n, red_ws, ctl, s);
+}
+
+__global__ void admm_finalize_generic_k(FinalizeArgs fa, AdmmCtl* ctl) {
+  if (ctl->active == 0) return;
+  if (threadIdx.x != 0) return;
+  double prc = 0, duc = 0, prz = 0, duz = 0;
+  int nc = 0, nz = 0;
+  for (int m = 0; m < fa.nmodes; ++m) {
+    const double* s = fa.slots[m];
+    if (fa.coupled[m]) {                        // eval_res_ADMM_coupl_case* (:1099-1210)
+      prc += sqrt(s[4]) / sqrt(s[1]);
+      const double sc = sqrt(s[5]);
+      duc += sc > 0 ? sqrt(s[6]) / sc : sqrt(s[6]);
+      ++nc;
+    }
+    if (fa.constrained[m]) {                    // eval_res_ADMM_constr (:1079-1096)
+      prz += sqrt(s[0]) / sqrt(s[1]);
+      const double sc = sqrt(s[2]);
+      duz += sc > 0 ? sqrt(s[3]) / sc : sqrt(s[3]);
+      ++nz;
+    }
+  }
+  if (nc) { prc /= nc; duc /= nc; }
+  if (nz) { prz /= nz; duz /= nz; }             // else 0 (:690-691)
+  ctl->res[0] = prc; ctl->res[1] = prz; ctl->res[2] = duc; ctl->res[3] = duz;
+  const int it = ctl->iters + 1;
+  ctl->iters = it;
+  ctl->active = (it < fa.max_inner && (prc > fa.tol_pr_coupl || prz > fa.tol_pr_constr ||
+                                       duc > fa.tol_du_coupl || duz > fa.tol_du_constr)) ? 1 : 0;
+}
+void admm_finalize_generic(const FinalizeArgs& fa, AdmmCtl* ctl, hipStream_t s) {
+  admm_finalize_generic_k<<<1, 64, 0, s>>>(fa, ctl);
+  AO_KERNEL_CHECK();
+}
+
+}  // namespace aoadmm

@@ -1,0 +1,365 @@
+// extern "C" boundary of libaoadmm_hip.so (include/aoadmm_hip.h).  No exception
+// leaves this file; every entry point returns a status and records the message.
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <new>
+
+#include "solver.h"
+
+using namespace aoadmm;
+
+struct aoadmm_ctx {
+  Engine* eng;
+};
+
+static thread_local std::string g_last_error;
+
+template <class F>
+static int guarded(F&& f) {
+  try {
+    f();
+    return AOADMM_OK;
+  } catch (const Error& e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    g_last_error = "host allocation failed";
+    return AOADMM_ERR_NOMEM;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return AOADMM_ERR_INVALID;
+  } catch (...) {
+    g_last_error = "unknown failure";
+    return AOADMM_ERR_INVALID;
+  }
+}
+
+#define CTX_OR_FAIL(ctx)                                   \
+  if (!(ctx) || !(ctx)->eng) {                             \
+    g_last_error = "null context";                         \
+    return AOADMM_ERR_INVALID;                             \
+  }
+
+extern "C" {
+
+int aoadmm_abi_version(void) { return AOADMM_ABI_VERSION; }
+const char* aoadmm_last_error(void) { return g_last_error.c_str(); }
+
+int aoadmm_device_count(int* n) {
+  return guarded([&] {
+    AO_REQUIRE(n != nullptr, "null pointer");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *n = (e == hipSuccess) ? c : 0;
+  });
+}
+
+int aoadmm_create(aoadmm_ctx** ctx, int device) {
+  return guarded([&] {
+    AO_REQUIRE(ctx != nullptr, "null pointer");
+    *ctx = nullptr;
+    Engine* e = new Engine(device);
+    aoadmm_ctx* c = new aoadmm_ctx;
+    c->eng = e;
+    *ctx = c;
+  });
+}
+
+int aoadmm_destroy(aoadmm_ctx* ctx) {
+  return guarded([&] {
+    if (!ctx) return;
+    delete ctx->eng;
+    delete ctx;
+  });
+}
+
+int aoadmm_synchronize(aoadmm_ctx* ctx) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_HIP(hipSetDevice(ctx->eng->device()));
+    AO_HIP(hipStreamSynchronize(ctx->eng->stream()));
+  });
+}
+
+int aoadmm_comm_unique_id(char id[128]) {
+  return guarded([&] {
+    AO_REQUIRE(id != nullptr, "null pointer");
+    ncclUniqueId uid;
+    ncclResult_t r = ncclGetUniqueId(&uid);
+    if (r != ncclSuccess) throw Error(AOADMM_ERR_RCCL, fmt("ncclGetUniqueId failed: %s", ncclGetErrorString(r)));
+    std::memset(id, 0, 128);
+    std::memcpy(id, &uid, sizeof(uid));
+  });
+}
+int aoadmm_comm_init_rank(aoadmm_ctx* ctx, const char id[128], int rank, int world) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->comm_init(id, rank, world); });
+}
+int aoadmm_comm_rank(aoadmm_ctx* ctx, int* rank, int* world) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    if (rank) *rank = ctx->eng->rank();
+    if (world) *world = ctx->eng->world();
+  });
+}
+
+int aoadmm_model_begin(aoadmm_ctx* ctx, int n_modes, int n_tensors, int n_couplings) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->model_begin(n_modes, n_tensors, n_couplings); });
+}
+int aoadmm_model_set_mode(aoadmm_ctx* ctx, int mode, int64_t rows, int rank) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->set_mode(mode, rows, rank); });
+}
+int aoadmm_model_set_mode_slabs(aoadmm_ctx* ctx, int mode, int K, const int64_t* rows_k, int rank) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(rows_k != nullptr, "null pointer");
+    ctx->eng->set_mode_slabs(mode, K, rows_k, rank);
+  });
+}
+int aoadmm_model_add_cp(aoadmm_ctx* ctx, int p, int n, const int* modes, double weight) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(modes != nullptr, "null pointer");
+    ctx->eng->add_cp(p, n, modes, weight);
+  });
+}
+int aoadmm_model_add_par2(aoadmm_ctx* ctx, int p, const int* modes3, double weight) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(modes3 != nullptr, "null pointer");
+    ctx->eng->add_par2(p, modes3, weight);
+  });
+}
+int aoadmm_model_set_constraint(aoadmm_ctx* ctx, int mode, int constraint, const double* params, int n_params,
+                                const double* Lmat) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(n_params == 0 || params != nullptr, "null parameters");
+    ctx->eng->set_constraint(mode, constraint, params, n_params, Lmat);
+  });
+}
+int aoadmm_model_set_coupling(aoadmm_ctx* ctx, int mode, int coupling, const double* H, int64_t hr, int64_t hc,
+                              const double* H2, int64_t h2r, int64_t h2c) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->set_coupling(mode, coupling, H, hr, hc, H2, h2r, h2c); });
+}
+int aoadmm_model_set_coupling_type(aoadmm_ctx* ctx, int coupling, int type) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->set_coupling_type(coupling, type); });
+}
+int aoadmm_model_set_ridge(aoadmm_ctx* ctx, const double* ridge) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->set_ridge(ridge); });
+}
+int aoadmm_model_end(aoadmm_ctx* ctx) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->model_end(); });
+}
+
+int aoadmm_tensor_upload(aoadmm_ctx* ctx, int p, const double* data, int precision) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(data != nullptr, "null data");
+    ctx->eng->tensor_upload(p, data, precision, 0, -1);
+  });
+}
+int aoadmm_tensor_upload_rows(aoadmm_ctx* ctx, int p, const double* block, int64_t row_offset, int64_t local_rows,
+                              int precision) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(block != nullptr && local_rows > 0, "null/empty block");
+    ctx->eng->tensor_upload(p, block, precision, row_offset, local_rows);
+  });
+}
+int aoadmm_par2_slab_upload(aoadmm_ctx* ctx, int p, int k, const double* Xk) {
+  CTX_OR_FAIL(ctx);
+  (void)p; (void)k; (void)Xk;
+  g_last_error = "PARAFAC2 blocks are not in the device path yet (use the MATLAB path)";
+  return AOADMM_ERR_UNSUPPORTED;
+}
+int aoadmm_tensor_synth(aoadmm_ctx* ctx, int p, int rank, uint64_t seed, double noise, int precision) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->tensor_synth(p, rank, seed, noise, precision); });
+}
+int aoadmm_tensor_normsq(aoadmm_ctx* ctx, int p, double* out) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(out != nullptr, "null pointer");
+    *out = ctx->eng->tensor_normsq(p);
+  });
+}
+
+int aoadmm_state_set(aoadmm_ctx* ctx, int field, int index, int slab, const double* host, int64_t rows,
+                     int64_t cols) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->state_set(field, index, slab, host, rows, cols); });
+}
+int aoadmm_state_get(aoadmm_ctx* ctx, int field, int index, int slab, double* host, int64_t rows, int64_t cols) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->state_get(field, index, slab, host, rows, cols); });
+}
+
+int aoadmm_solve(aoadmm_ctx* ctx, const aoadmm_options* opt, aoadmm_result* out) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(opt != nullptr && out != nullptr, "null options/result");
+    ctx->eng->solve(*opt, out);
+  });
+}
+int aoadmm_resident_mttkrp(aoadmm_ctx* ctx, int p, int tensor_mode, double* out_host_or_null, float* elapsed_ms) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->resident_mttkrp(p, tensor_mode, out_host_or_null, elapsed_ms); });
+}
+int aoadmm_kernel_stats(aoadmm_ctx* ctx, int reset, double* contract_ms, int64_t* contract_launches,
+                        double* contract_bytes, double* contract_flops) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->kernel_stats(reset, contract_ms, contract_launches, contract_bytes, contract_flops); });
+}
+
+// ---------------------------------------------------------------------------
+// op level
+// ---------------------------------------------------------------------------
+static void h2d(DevBuf& b, const double* h, int64_t n, hipStream_t s) {
+  b.alloc((size_t)n * sizeof(double));
+  AO_HIP(hipMemcpyAsync(b.p, h, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+}
+static void d2h(double* h, const DevBuf& b, int64_t n, hipStream_t s) {
+  AO_HIP(hipMemcpyAsync(h, b.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+  AO_HIP(hipStreamSynchronize(s));
+}
+
+int aoadmm_op_mttkrp(aoadmm_ctx* ctx, const double* X, int ndims, const int64_t* dims, const double* const* U, int R,
+                     int n, int precision, double* out) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(X && dims && U && out, "null pointer");
+    AO_REQUIRE(ndims >= 2 && ndims <= 8 && n >= 0 && n < ndims, "bad order/mode");
+    Engine& e = *ctx->eng;
+    AO_HIP(hipSetDevice(e.device()));
+    CpBlock blk;
+    e.block_upload(blk, ndims, dims, X, precision, 0, dims[0]);
+    std::vector<DevBuf> fac(ndims);
+    FactorRef refs[8];
+    for (int m = 0; m < ndims; ++m) {
+      AO_REQUIRE(U[m] != nullptr, "null factor");
+      h2d(fac[m], U[m], dims[m] * R, e.stream());
+      refs[m] = FactorRef{fac[m].d(), dims[m], 1};
+    }
+    DevBuf o;
+    o.alloc((size_t)dims[n] * R * sizeof(double));
+    e.block_mttkrp(blk, n, refs, R, 1.0, o.d(), dims[n], false, nullptr, 0);
+    d2h(out, o, dims[n] * R, e.stream());
+  });
+}
+
+int aoadmm_op_gram(aoadmm_ctx* ctx, const double* F, int64_t rows, int R, double* out) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(F && out && rows > 0 && R > 0 && R <= kMaxRank, "bad arguments");
+    Engine& e = *ctx->eng;
+    AO_HIP(hipSetDevice(e.device()));
+    DevBuf f, g, ws;
+    h2d(f, F, rows * R, e.stream());
+    g.alloc((size_t)R * R * 8);
+    ws.alloc(atb_ws_bytes(rows, R, R));
+    atb_small(g.d(), f.d(), rows, f.d(), rows, rows, R, R, ws.d(), nullptr, e.stream());
+    d2h(out, g, (int64_t)R * R, e.stream());
+  });
+}
+
+int aoadmm_op_chol(aoadmm_ctx* ctx, const double* B, int R, double* L) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(B && L && R > 0 && R <= kMaxRank, "bad arguments");
+    Engine& e = *ctx->eng;
+    AO_HIP(hipSetDevice(e.device()));
+    DevBuf b, l, c;
+    h2d(b, B, (int64_t)R * R, e.stream());
+    l.alloc((size_t)R * R * 8);
+    c.alloc(sizeof(AdmmCtl));
+    AO_HIP(hipMemsetAsync(c.p, 0, sizeof(AdmmCtl), e.stream()));
+    AO_HIP(hipMemsetAsync(l.p, 0, (size_t)R * R * 8, e.stream()));
+    chol_only(l.d(), b.d(), R, c.as<AdmmCtl>(), e.stream());
+    AdmmCtl h;
+    AO_HIP(hipMemcpyAsync(&h, c.p, sizeof h, hipMemcpyDeviceToHost, e.stream()));
+    AO_HIP(hipStreamSynchronize(e.stream()));
+    if (h.notpd) throw Error(AOADMM_ERR_NOT_PD, "Matrix must be positive definite.");
+    d2h(L, l, (int64_t)R * R, e.stream());
+  });
+}
+
+static ProxSpec make_spec(int constraint, const double* params, int np) {
+  ProxSpec ps;
+  ps.type = constraint;
+  if (np > 0) ps.p0 = params[0];
+  if (np > 1) ps.p1 = params[1];
+  return ps;
+}
+
+int aoadmm_op_prox(aoadmm_ctx* ctx, int constraint, const double* params, int n_params, const double* Lmat,
+                   const double* X, int64_t rows, int R, double rho, double* out) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    (void)Lmat;
+    AO_REQUIRE(X && out && rows > 0 && R > 0 && R <= kMaxRank, "bad arguments");
+    Engine& e = *ctx->eng;
+    AO_HIP(hipSetDevice(e.device()));
+    DevBuf x, z, r, ws;
+    h2d(x, X, rows * R, e.stream());
+    z.alloc((size_t)rows * R * 8);
+    h2d(r, &rho, 1, e.stream());
+    ws.alloc(prox_ws_bytes(constraint, rows, R));
+    prox_apply(make_spec(constraint, params, n_params), x.d(), rows, z.d(), rows, rows, R, r.d(), 1.0, ws.d(), nullptr,
+               e.stream());
+    d2h(out, z, rows * R, e.stream());
+  });
+}
+
+int aoadmm_op_admm_constrained(aoadmm_ctx* ctx, const double* A, const double* Bsys, double rho, int constraint,
+                               const double* params, int n_params, const double* Lmat, int64_t rows, int R,
+                               int max_inner, double tol_pr, double tol_du, double* fac, double* Z, double* mu,
+                               int* inner_iters) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    (void)Lmat;
+    AO_REQUIRE(A && Bsys && fac && Z && mu && rows > 0 && R > 0 && R <= kMaxRank && max_inner >= 1, "bad arguments");
+    Engine& e = *ctx->eng;
+    hipStream_t s = e.stream();
+    AO_HIP(hipSetDevice(e.device()));
+    DevBuf a, b, l, rh, f, z, m, part, V, Zn, ws, ctl, Cd;
+    h2d(a, A, rows * R, s); h2d(b, Bsys, (int64_t)R * R, s);
+    h2d(f, fac, rows * R, s); h2d(z, Z, rows * R, s); h2d(m, mu, rows * R, s);
+    l.alloc((size_t)R * R * 8); rh.alloc(64); Cd.alloc((size_t)R * R * 8);
+    part.alloc((size_t)admm_partials(rows) * 4 * 8 + 2048);
+    V.alloc((size_t)rows * R * 8); Zn.alloc((size_t)rows * R * 8);
+    ws.alloc(prox_ws_bytes(constraint, rows, R));
+    ctl.alloc(sizeof(AdmmCtl));
+    AO_HIP(hipMemsetAsync(ctl.p, 0, sizeof(AdmmCtl), s));
+    // B + rho/2*I and its Cholesky (cmtf_fun_AOADMM.m:141-142): feed sys_build with C = Bsys, w = 1
+    // but keep the caller's rho: do it by hand
+    std::vector<double> Bh(Bsys, Bsys + (size_t)R * R);
+    for (int i = 0; i < R; ++i) Bh[i + (size_t)R * i] += rho / 2;
+    DevBuf bb;
+    h2d(bb, Bh.data(), (int64_t)R * R, s);
+    h2d(rh, &rho, 1, s);
+    AO_HIP(hipStreamSynchronize(s));
+    chol_only(l.d(), bb.d(), R, ctl.as<AdmmCtl>(), s);
+    ctl_reset(ctl.as<AdmmCtl>(), s);
+    AdmmMode am;
+    am.A = a.d(); am.L = l.d(); am.rho = rh.d(); am.fac = f.d(); am.Z = z.d(); am.mu = m.d();
+    am.rows = rows; am.R = R; am.prox = make_spec(constraint, params, n_params);
+    for (int it = 0; it < max_inner; ++it)
+      admm_constrained_iteration(am, part.d(), V.d(), Zn.d(), ws.d(), ctl.as<AdmmCtl>(), max_inner, tol_pr, tol_du, s);
+    AdmmCtl h;
+    AO_HIP(hipMemcpyAsync(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost, s));
+    AO_HIP(hipStreamSynchronize(s));
+    if (h.notpd) throw Error(AOADMM_ERR_NOT_PD, "Matrix must be positive definite.");
+    if (inner_iters) *inner_iters = h.iters;
+    d2h(fac, f, rows * R, s); d2h(Z, z, rows * R, s); d2h(mu, m, rows * R, s);
+  });
+}
+
+}  // extern "C"

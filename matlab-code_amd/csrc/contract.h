@@ -1,0 +1,61 @@
+// Tensor-pass kernels: partial contraction of a dense tensor with one factor
+// matrix on the matrix cores, and the small reductions that finish an MTTKRP.
+#pragma once
+#include "common.h"
+
+namespace aoadmm {
+
+// A dense block resident in HBM, first dimension padded (zeros) to `pad0`
+// elements so that every column of every unfolding starts 16-byte aligned.
+struct DenseTensor {
+  int prec = AOADMM_PREC_F64;
+  int nd = 0;
+  int64_t dims[8] = {0};   // logical sizes (local sizes when row-sharded)
+  int64_t pad0 = 0;        // padded first dimension (multiple of 4 for f32, 2 for f64)
+  DevBuf data;             // pad0 * dims[1] * ... elements of float/double
+  int64_t elems_padded() const {
+    int64_t n = pad0;
+    for (int i = 1; i < nd; ++i) n *= dims[i];
+    return n;
+  }
+  size_t elem_size() const { return prec == AOADMM_PREC_F32 ? 4 : 8; }
+};
+
+// Description of one batched "contiguous-M" contraction
+//   T[b][m][r] = sum_{c<C} X[b*batch_stride + m + ld*c] * F[c][r]
+// (m contiguous in memory).  T is fp64, row-major [nchunk][nbatch*M][R].
+struct ContractPlan {
+  int64_t nbatch, batch_stride, M, ld, C;
+  int R;
+  int nchunk;          // split of the reduction (bounds f32 accumulation length)
+  int64_t trows() const { return nbatch * M; }
+  size_t t_bytes() const { return (size_t)nchunk * trows() * R * sizeof(double); }
+  size_t frag_bytes(int prec) const;
+  double algorithmic_bytes(int prec) const {   // tensor read once + T written once
+    return (double)nbatch * M * C * (prec == AOADMM_PREC_F32 ? 4.0 : 8.0) + (double)t_bytes();
+  }
+  double flops() const { return 2.0 * nbatch * M * C * R; }
+};
+
+ContractPlan make_plan(int64_t nbatch, int64_t batch_stride, int64_t M, int64_t ld, int64_t C, int R,
+                       int prec);
+
+// F: device fp64, column-major (C x R) with leading dimension ldF.
+void launch_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
+                     void* frag_ws, double* T, hipStream_t s);
+
+// out(b,r) = scale * sum_a sum_chunk T[chunk][a + Apad*b][r] * Fa(a,r)      (a < A)
+void launch_reduce_inner(const double* T, int nchunk, int64_t trows, int64_t A, int64_t Apad,
+                         int64_t B, int R, const double* Fa, int64_t ldFa, double scale,
+                         double* out, int64_t ldOut, hipStream_t s);
+// out(a,r) = scale * sum_b sum_chunk T[chunk][a + Apad*b][r] * Fb(b,r)      (a < A)
+// scratch must hold reduce_outer_scratch_bytes().
+size_t reduce_outer_scratch_bytes(int64_t A, int64_t B, int R);
+void launch_reduce_outer(const double* T, int nchunk, int64_t trows, int64_t A, int64_t Apad,
+                         int64_t B, int R, const double* Fb, int64_t ldFb, double scale,
+                         double* out, int64_t ldOut, double* scratch, hipStream_t s);
+// out(a,r) = scale * sum_chunk T[chunk][a][r]     (matrix blocks: nothing left to reduce)
+void launch_t_to_colmajor(const double* T, int nchunk, int64_t trows, int64_t A, int R, double scale,
+                          double* out, int64_t ldOut, hipStream_t s);
+
+}  // namespace aoadmm

@@ -1,0 +1,450 @@
+// Tensor-pass kernels for gfx950 (MI355X).
+//
+// The hot operation of AO-ADMM is mttkrp(X,U,n) (reference call site
+// functions/cmtf_fun_AOADMM.m:97, third-party Tensor Toolbox).  Here it is
+// split into
+//   (1) one streaming pass over the tensor that contracts ONE mode with its
+//       factor matrix on the matrix cores (contract_f32 / contract_f64), giving
+//       T[m][r], and
+//   (2) a small elementwise-multiply-and-reduce over T (reduce_inner / _outer).
+// (1) reads every tensor element exactly once with 16-byte coalesced loads
+// straight into MFMA operand registers (the unfolding's row index is the
+// contiguous one, so no LDS staging is needed); T is ~R*8/(C*s) of the tensor
+// bytes.  T is reusable for two modes (dimension tree), which is what cuts
+// the tensor reads per outer iteration from 3 to 2.
+//
+// f32: v_mfma_f32_32x32x2_f32, lane l holds A[row l&31][k=l>>5], B[k=l>>5][col l&31];
+//      a lane's float4 load gives rows 4*(l&31)+v (v=0..3) of column k, i.e. four
+//      MFMA row tiles {4*rho+v}.  f64: v_mfma_f64_16x16x4_f64, lane l holds
+//      A[row l&15][k=l>>4]; a double2 load gives rows 2*(l&15)+v.
+#include "contract.h"
+
+namespace aoadmm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int kTileRows = 128;     // rows of the unfolding per wave
+static constexpr int kGroup = 8;          // reduction columns per pipeline stage
+
+// ---------------------------------------------------------------------------
+// operand packing: factor matrix (C x R, fp64 col-major) -> MFMA B fragments
+// ---------------------------------------------------------------------------
+// f32 layout: frag[nt][g][lane][s], value F[8g + 2s + (lane>>5)][32nt + (lane&31)]
+__global__ void pack_frag_f32(const double* __restrict__ F, int64_t ldF, int64_t C, int R, int NT,
+                              int64_t Cg, float* __restrict__ frag) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over nt*Cg*64*4
+  int64_t total = (int64_t)NT * Cg * 256;
+  if (idx >= total) return;
+  int s = idx & 3;
+  int lane = (idx >> 2) & 63;
+  int64_t g = (idx >> 8) % Cg;
+  int nt = (int)((idx >> 8) / Cg);
+  int64_t c = 8 * g + 2 * s + (lane >> 5);
+  int r = 32 * nt + (lane & 31);
+  float v = 0.f;
+  if (c < C && r < R) v = (float)F[c + ldF * r];
+  frag[idx] = v;
+}
+// f64 layout: frag[nt][g][lane][e], value F[8g + 4e + (lane>>4)][16nt + (lane&15)]
+__global__ void pack_frag_f64(const double* __restrict__ F, int64_t ldF, int64_t C, int R, int NT,
+                              int64_t Cg, double* __restrict__ frag) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over nt*Cg*64*2
+  int64_t total = (int64_t)NT * Cg * 128;
+  if (idx >= total) return;
+  int e = idx & 1;
+  int lane = (idx >> 1) & 63;
+  int64_t g = (idx >> 7) % Cg;
+  int nt = (int)((idx >> 7) / Cg);
+  int64_t c = 8 * g + 4 * e + (lane >> 4);
+  int r = 16 * nt + (lane & 15);
+  double v = 0.0;
+  if (c < C && r < R) v = F[c + ldF * r];
+  frag[idx] = v;
+}
+
+// ---------------------------------------------------------------------------
+// f32 contraction
+// ---------------------------------------------------------------------------
+struct KArgs {
+  const void* X;
+  const void* frag;
+  double* T;
+  int64_t tiles_per_batch, ntiles, batch_stride, M, ld, C, Cg, trows;
+  int groups_per_chunk, R;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void contract_f32(KArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wt >= a.ntiles) return;                       // wave-uniform
+  const int chunk = blockIdx.y;
+  const int64_t b = wt / a.tiles_per_batch;
+  const int64_t m0 = (wt - b * a.tiles_per_batch) * kTileRows;
+  const int r4 = lane & 31, h = lane >> 5;
+  int64_t row = m0 + 4 * r4;
+  if (row >= a.M) row = m0;                          // padding lanes re-read a valid row; never stored
+  const int64_t g0 = (int64_t)chunk * a.groups_per_chunk;
+  int64_t g1 = g0 + a.groups_per_chunk;
+  if (g1 > a.Cg) g1 = a.Cg;
+  const int64_t gfull = (a.C / kGroup < g1) ? a.C / kGroup : g1;   // groups with all 8 columns valid
+  const float* X = reinterpret_cast<const float*>(a.X);
+  const float* xp = X + b * a.batch_stride + row + (kGroup * g0 + h) * a.ld;
+  const int64_t ld2 = 2 * a.ld;
+  const f32x4* fp = reinterpret_cast<const f32x4*>(a.frag) + g0 * 64 + lane;
+  const int64_t fnt = a.Cg * 64;                     // f32x4 stride between N tiles
+
+  f32x16 acc[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nt][v][i] = 0.f;
+
+  f32x4 xa[4], fa[NT];
+  int64_t g = g0;
+  if (g < gfull) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const f32x4*>(xp + s * ld2);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) fa[nt] = fp[nt * fnt];
+  }
+  for (; g < gfull; ++g) {
+    f32x4 xb[4], fb[NT];
+    const float* xn = xp + kGroup * a.ld;
+    const f32x4* fn = fp + 64;
+    if (g + 1 < gfull) {                              // wave-uniform prefetch of the next stage
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xb[s] = *reinterpret_cast<const f32x4*>(xn + s * ld2);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[nt] = fn[nt * fnt];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          acc[nt][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s][v], fa[nt][s], acc[nt][v], 0, 0, 0);
+    xp = xn;
+    fp = fn;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xa[s] = xb[s];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) fa[nt] = fb[nt];
+  }
+  // ragged tail group: columns >= C are clamped (finite data) and meet zero B fragments
+  if (g < g1) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      int64_t c = kGroup * g + 2 * s + h;
+      if (c >= a.C) c = a.C - 1;
+      const float* p = X + b * a.batch_stride + row + c * a.ld;
+      xa[s] = *reinterpret_cast<const f32x4*>(p);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) fa[nt] = (reinterpret_cast<const f32x4*>(a.frag) + g * 64 + lane)[nt * fnt];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          acc[nt][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s][v], fa[nt][s], acc[nt][v], 0, 0, 0);
+  }
+  // epilogue: C/D map col = lane&31, row rho = (reg&3) + 8*(reg>>2) + 4*(lane>>5); tile row = 4*rho+v
+  double* Tc = a.T + ((int64_t)chunk * a.trows + b * a.M) * a.R;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r = 32 * nt + r4;
+    if (r < a.R) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int rho = (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int64_t m = m0 + 4 * rho + v;
+          if (m < a.M) Tc[m * a.R + r] = (double)acc[nt][v][i];
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// f64 contraction (parity mode)
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void contract_f64(KArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wt >= a.ntiles) return;
+  const int chunk = blockIdx.y;
+  const int64_t b = wt / a.tiles_per_batch;
+  const int64_t m0 = (wt - b * a.tiles_per_batch) * kTileRows;
+  const int r2 = lane & 15, q = lane >> 4;
+  int64_t rowj[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    rowj[j] = m0 + 32 * j + 2 * r2;
+    if (rowj[j] >= a.M) rowj[j] = m0;
+  }
+  const int64_t g0 = (int64_t)chunk * a.groups_per_chunk;
+  int64_t g1 = g0 + a.groups_per_chunk;
+  if (g1 > a.Cg) g1 = a.Cg;
+  const int64_t gfull = (a.C / kGroup < g1) ? a.C / kGroup : g1;
+  const double* X = reinterpret_cast<const double*>(a.X) + b * a.batch_stride;
+  const f64x2* fbase = reinterpret_cast<const f64x2*>(a.frag);
+  const int64_t fnt = a.Cg * 64;
+
+  f64x4 acc[4][2][NT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][v][nt][i] = 0.0;
+
+  auto stage = [&](int64_t g, bool clamp) {
+    f64x2 x[2][4];
+    f64x2 f[NT];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      int64_t c = kGroup * g + 4 * e + q;
+      if (clamp && c >= a.C) c = a.C - 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[e][j] = *reinterpret_cast<const f64x2*>(X + rowj[j] + c * a.ld);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) f[nt] = fbase[nt * fnt + g * 64 + lane];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[j][v][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[e][j][v], f[nt][e], acc[j][v][nt], 0, 0, 0);
+  };
+#pragma unroll 2
+  for (int64_t g = g0; g < gfull; ++g) stage(g, false);
+  if (gfull < g1) stage(gfull, true);
+
+  // C/D map (f64!): col = lane&15, row rho = (lane>>4) + 4*reg ; tile row = 32j + 2*rho + v
+  double* Tc = a.T + ((int64_t)chunk * a.trows + b * a.M) * a.R;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r = 16 * nt + r2;
+    if (r < a.R) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int rho = q + 4 * i;
+            const int64_t m = m0 + 32 * j + 2 * rho + v;
+            if (m < a.M) Tc[m * a.R + r] = acc[j][v][nt][i];
+          }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int nt_of(int R, int prec) {
+  const int w = prec == AOADMM_PREC_F32 ? 32 : 16;
+  return (R + w - 1) / w;
+}
+
+size_t ContractPlan::frag_bytes(int prec) const {
+  const int64_t Cg = cdiv(C, kGroup);
+  return (size_t)nt_of(R, prec) * Cg * 1024;
+}
+
+ContractPlan make_plan(int64_t nbatch, int64_t batch_stride, int64_t M, int64_t ld, int64_t C, int R,
+                       int prec) {
+  ContractPlan p;
+  p.nbatch = nbatch; p.batch_stride = batch_stride; p.M = M; p.ld = ld; p.C = C; p.R = R;
+  const int64_t Cg = cdiv(C, kGroup);
+  const int64_t ntiles = nbatch * cdiv(M, kTileRows);
+  int64_t nchunk = 1;
+  // f32 accumulates in fp32 inside the MFMA: keep one accumulation run <= 2048 terms;
+  // partial sums of different chunks are added in fp64 by the reduce kernels.
+  if (prec == AOADMM_PREC_F32) nchunk = cdiv(Cg, 256);
+  // few row tiles (short mode): split the reduction to fill the 256 CUs
+  if (ntiles < 2048) {
+    int64_t want = cdiv(2048, ntiles);
+    int64_t maxc = Cg / 16 > 0 ? Cg / 16 : 1;       // keep >= 128 columns per chunk
+    if (want > maxc) want = maxc;
+    if (want > nchunk) nchunk = want;
+  }
+  if (nchunk > 65535) nchunk = 65535;
+  p.nchunk = (int)nchunk;
+  return p;
+}
+
+void launch_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
+                     void* frag_ws, double* T, hipStream_t s) {
+  AO_REQUIRE(pl.R >= 1 && pl.R <= kMaxRank, "rank %d outside [1,%d]", pl.R, kMaxRank);
+  const int64_t Cg = cdiv(pl.C, kGroup);
+  const int NT = nt_of(pl.R, prec);
+  KArgs a;
+  a.X = X; a.frag = frag_ws; a.T = T;
+  a.tiles_per_batch = cdiv(pl.M, kTileRows);
+  a.ntiles = pl.nbatch * a.tiles_per_batch;
+  a.batch_stride = pl.batch_stride; a.M = pl.M; a.ld = pl.ld; a.C = pl.C; a.Cg = Cg;
+  a.trows = pl.trows();
+  a.groups_per_chunk = (int)cdiv(Cg, pl.nchunk);
+  a.R = pl.R;
+  AO_REQUIRE(a.ntiles > 0 && pl.C > 0, "empty contraction");
+  dim3 grid((unsigned)cdiv(a.ntiles, 4), (unsigned)pl.nchunk);
+  AO_REQUIRE(cdiv(a.ntiles, 4) < (int64_t)2147483647, "tensor too large for one launch");
+  if (prec == AOADMM_PREC_F32) {
+    AO_REQUIRE(pl.ld % 4 == 0 && pl.M % 4 == 0 && pl.batch_stride % 4 == 0, "f32 layout must be padded to 4");
+    int64_t total = (int64_t)NT * Cg * 256;
+    pack_frag_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (float*)frag_ws);
+    AO_KERNEL_CHECK();
+    if (NT == 1) contract_f32<1><<<grid, 256, 0, s>>>(a);
+    else if (NT == 2) contract_f32<2><<<grid, 256, 0, s>>>(a);
+    else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
+  } else {
+    AO_REQUIRE(pl.ld % 2 == 0 && pl.M % 2 == 0 && pl.batch_stride % 2 == 0, "f64 layout must be padded to 2");
+    int64_t total = (int64_t)NT * Cg * 128;
+    pack_frag_f64<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (double*)frag_ws);
+    AO_KERNEL_CHECK();
+    if (NT == 1) contract_f64<1><<<grid, 256, 0, s>>>(a);
+    else if (NT == 2) contract_f64<2><<<grid, 256, 0, s>>>(a);
+    else if (NT == 3) contract_f64<3><<<grid, 256, 0, s>>>(a);
+    else if (NT == 4) contract_f64<4><<<grid, 256, 0, s>>>(a);
+    else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
+  }
+  AO_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// reductions over T (fp64, deterministic summation order)
+// ---------------------------------------------------------------------------
+// one block per b; thread t -> (al = t / R, r = t % R); fixed-order LDS tree at the end
+__global__ void reduce_inner_k(const double* __restrict__ T, int nchunk, int64_t trows, int64_t A,
+                               int64_t Apad, int R, const double* __restrict__ Fa, int64_t ldFa,
+                               double scale, double* __restrict__ out, int64_t ldOut) {
+  extern __shared__ double sh[];
+  const int64_t b = blockIdx.x;
+  const int nA = blockDim.x / R;
+  const int t = threadIdx.x;
+  const int al = t / R, r = t - al * R;
+  double sum = 0.0;
+  if (al < nA) {
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const double* Tb = T + ((int64_t)ch * trows + Apad * b) * R;
+      for (int64_t a = al; a < A; a += nA) sum += Tb[a * R + r] * Fa[a + ldFa * r];
+    }
+    sh[t] = sum;
+  }
+  __syncthreads();
+  if (t < R) {
+    double tot = 0.0;
+    for (int i = 0; i < nA; ++i) tot += sh[i * R + t];
+    out[b + ldOut * t] = scale * tot;
+  }
+}
+
+void launch_reduce_inner(const double* T, int nchunk, int64_t trows, int64_t A, int64_t Apad,
+                         int64_t B, int R, const double* Fa, int64_t ldFa, double scale,
+                         double* out, int64_t ldOut, hipStream_t s) {
+  int threads = 256 / R * R;
+  if (threads < R) threads = R;
+  reduce_inner_k<<<(unsigned)B, threads, threads * sizeof(double), s>>>(T, nchunk, trows, A, Apad, R, Fa, ldFa,
+                                                                       scale, out, ldOut);
+  AO_KERNEL_CHECK();
+}
+
+static void outer_geometry(int64_t A, int64_t B, int R, int& TA, int64_t& nblkA, int& SB) {
+  TA = 256 / R;
+  if (TA < 1) TA = 1;
+  nblkA = cdiv(A, TA);
+  int64_t sb = cdiv(1024, nblkA);
+  if (sb > 64) sb = 64;
+  if (sb > B) sb = B;
+  if (sb < 1) sb = 1;
+  SB = (int)sb;
+}
+
+size_t reduce_outer_scratch_bytes(int64_t A, int64_t B, int R) {
+  int TA, SB; int64_t nb;
+  outer_geometry(A, B, R, TA, nb, SB);
+  return (size_t)SB * A * R * sizeof(double);
+}
+
+__global__ void reduce_outer_k(const double* __restrict__ T, int nchunk, int64_t trows, int64_t A,
+                               int64_t Apad, int64_t B, int R, int TA, const double* __restrict__ Fb,
+                               int64_t ldFb, double* __restrict__ part) {
+  const int t = threadIdx.x;
+  const int al = t / R, r = t - al * R;
+  const int64_t a = (int64_t)blockIdx.x * TA + al;
+  const int SB = gridDim.y, sb = blockIdx.y;
+  const int64_t bper = (B + SB - 1) / SB;
+  const int64_t b0 = sb * bper;
+  int64_t b1 = b0 + bper;
+  if (b1 > B) b1 = B;
+  if (al >= TA || a >= A) return;
+  double sum = 0.0;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const double* Tc = T + (int64_t)ch * trows * R + a * R + r;
+#pragma unroll 4
+    for (int64_t b = b0; b < b1; ++b) sum += Tc[Apad * b * R] * Fb[b + ldFb * r];
+  }
+  part[((int64_t)sb * A + a) * R + r] = sum;
+}
+
+__global__ void reduce_outer_fin(const double* __restrict__ part, int SB, int64_t A, int R, double scale,
+                                 double* __restrict__ out, int64_t ldOut) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= A * R) return;
+  const int64_t a = idx / R;
+  const int r = (int)(idx - a * R);
+  double tot = 0.0;
+  for (int s = 0; s < SB; ++s) tot += part[(int64_t)s * A * R + idx];
+  out[a + ldOut * r] = scale * tot;
+}
+
+void launch_reduce_outer(const double* T, int nchunk, int64_t trows, int64_t A, int64_t Apad,
+                         int64_t B, int R, const double* Fb, int64_t ldFb, double scale,
+                         double* out, int64_t ldOut, double* scratch, hipStream_t s) {
+  int TA, SB; int64_t nb;
+  outer_geometry(A, B, R, TA, nb, SB);
+  int threads = TA * R;
+  threads = (threads + 63) / 64 * 64;
+  reduce_outer_k<<<dim3((unsigned)nb, (unsigned)SB), threads, 0, s>>>(T, nchunk, trows, A, Apad, B, R, TA, Fb, ldFb,
+                                                                     scratch);
+  AO_KERNEL_CHECK();
+  reduce_outer_fin<<<(unsigned)cdiv(A * R, 256), 256, 0, s>>>(scratch, SB, A, R, scale, out, ldOut);
+  AO_KERNEL_CHECK();
+}
+
+__global__ void t_to_colmajor_k(const double* __restrict__ T, int nchunk, int64_t trows, int64_t A, int R,
+                                double scale, double* __restrict__ out, int64_t ldOut) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= A * R) return;
+  const int64_t a = idx / R;
+  const int r = (int)(idx - a * R);
+  double tot = 0.0;
+  for (int ch = 0; ch < nchunk; ++ch) tot += T[(int64_t)ch * trows * R + idx];
+  out[a + ldOut * r] = scale * tot;
+}
+
+void launch_t_to_colmajor(const double* T, int nchunk, int64_t trows, int64_t A, int R, double scale,
+                          double* out, int64_t ldOut, hipStream_t s) {
+  t_to_colmajor_k<<<(unsigned)cdiv(A * R, 256), 256, 0, s>>>(T, nchunk, trows, A, R, scale, out, ldOut);
+  AO_KERNEL_CHECK();
+}
+
+}  // namespace aoadmm

@@ -1,0 +1,45 @@
+// Data movement / generation helpers: padded upload, transposition, synthetic
+// tensors generated in HBM, norms and regulariser values.
+#pragma once
+#include "common.h"
+#include "contract.h"
+#include "small.h"
+
+namespace aoadmm {
+
+// dst (padded, prec) <- src (device fp64, unpadded column-major rows x cols), for a column range
+void pad_convert(void* dst, int prec, int64_t pad_rows, const double* src, int64_t rows, int64_t cols,
+                 int64_t dst_col0, hipStream_t s);
+// dst (padded pad_c x rows, prec) = transpose of src (device fp64 rows x cols)
+void transpose_convert(void* dst, int prec, int64_t pad_c, const double* src, int64_t rows, int64_t cols,
+                       hipStream_t s);
+// sum of squares of a padded tensor (padding is zero) -> slot (fp64), deterministic
+void tensor_sumsq(double* slot, const void* X, int prec, int64_t n, double* ws, hipStream_t s);
+// X *= alpha
+void tensor_scale(void* X, int prec, int64_t n, double alpha, hipStream_t s);
+
+// synthetic CP data: element (i,j,k) of the local block with global row i+row0:
+//   clean = sum_r A(i,r) B(j,r) C(k,r), A/B/C ~ U[0,1) from a counter-based generator;
+//   noise ~ N(0,1) from the same generator family.
+// pass 1 (acc != null): accumulate sum clean^2 and sum noise^2 into acc[0], acc[1] partial buffers;
+// pass 2: write X = clean + sigma*noise.
+struct SynthArgs {
+  int64_t I_loc, I_pad, J, K, row0, I_full;
+  int R;
+  uint64_t seed;
+};
+void synth_factors(double* A, double* B, double* C, const SynthArgs& a, hipStream_t s);   // fp64 col-major, full sizes
+void synth_norms(double* out3, const double* A, const double* B, const double* C, const SynthArgs& a,
+                 double* ws, hipStream_t s);
+void synth_write(void* X, int prec, const double* A, const double* B, const double* C, const SynthArgs& a,
+                 double sigma, double inv_norm, hipStream_t s);
+size_t synth_ws_bytes();
+
+// regulariser value of constraints_to_prox.m (reg_func) on a factor matrix -> slot
+void reg_value(double* slot, int type, double p0, const double* X, int64_t rows, int R, double* ws,
+               hipStream_t s);
+
+// uniform [0,1) fill (device RNG; used by tests/bench for factor initialisation on device)
+void fill_uniform(double* x, int64_t n, uint64_t seed, hipStream_t s);
+
+}  // namespace aoadmm

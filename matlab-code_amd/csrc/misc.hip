@@ -1,0 +1,236 @@
+// Data movement / generation helpers (see misc.h).
+#include "misc.h"
+
+namespace aoadmm {
+
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void pad_convert_k(T* dst, int64_t pad_rows, const double* src, int64_t rows, int64_t cols,
+                              int64_t dst_col0) {
+  const int64_t total = pad_rows * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx % pad_rows, c = idx / pad_rows;
+    const double v = i < rows ? src[i + rows * c] : 0.0;
+    dst[i + pad_rows * (dst_col0 + c)] = (T)v;
+  }
+}
+void pad_convert(void* dst, int prec, int64_t pad_rows, const double* src, int64_t rows, int64_t cols,
+                 int64_t dst_col0, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return;
+  int64_t blocks = cdiv(pad_rows * cols, 256);
+  if (blocks > 65536) blocks = 65536;
+  if (prec == AOADMM_PREC_F32)
+    pad_convert_k<float><<<(unsigned)blocks, 256, 0, s>>>((float*)dst, pad_rows, src, rows, cols, dst_col0);
+  else
+    pad_convert_k<double><<<(unsigned)blocks, 256, 0, s>>>((double*)dst, pad_rows, src, rows, cols, dst_col0);
+  AO_KERNEL_CHECK();
+}
+
+template <typename T>
+__global__ void transpose_convert_k(T* dst, int64_t pad_c, const double* src, int64_t rows, int64_t cols) {
+  // dst(c, i) = src(i, c); dst leading dim pad_c (rows of dst = cols of src, zero padded)
+  const int64_t total = pad_c * rows;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = idx % pad_c, i = idx / pad_c;
+    dst[idx] = (T)(c < cols ? src[i + rows * c] : 0.0);
+  }
+}
+void transpose_convert(void* dst, int prec, int64_t pad_c, const double* src, int64_t rows, int64_t cols,
+                       hipStream_t s) {
+  int64_t blocks = cdiv(pad_c * rows, 256);
+  if (blocks > 65536) blocks = 65536;
+  if (blocks < 1) return;
+  if (prec == AOADMM_PREC_F32)
+    transpose_convert_k<float><<<(unsigned)blocks, 256, 0, s>>>((float*)dst, pad_c, src, rows, cols);
+  else
+    transpose_convert_k<double><<<(unsigned)blocks, 256, 0, s>>>((double*)dst, pad_c, src, rows, cols);
+  AO_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+static constexpr int kNormBlocks = 1024;
+
+__device__ __forceinline__ double block_reduce256(double v, double* sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+template <typename T>
+__global__ void tensor_sumsq_k(double* ws, const T* X, int64_t n) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = (double)X[i];
+    acc += v * v;
+  }
+  const double t = block_reduce256(acc, sh);
+  if (threadIdx.x == 0) ws[blockIdx.x] = t;
+}
+__global__ void sum_ws_k(double* slot, const double* ws, int nb, int stride, int nout) {
+  if ((int)threadIdx.x < nout) {
+    double t = 0.0;
+    for (int b = 0; b < nb; ++b) t += ws[(int64_t)b * stride + threadIdx.x];
+    slot[threadIdx.x] = t;
+  }
+}
+void tensor_sumsq(double* slot, const void* X, int prec, int64_t n, double* ws, hipStream_t s) {
+  if (prec == AOADMM_PREC_F32) tensor_sumsq_k<float><<<kNormBlocks, 256, 0, s>>>(ws, (const float*)X, n);
+  else tensor_sumsq_k<double><<<kNormBlocks, 256, 0, s>>>(ws, (const double*)X, n);
+  AO_KERNEL_CHECK();
+  sum_ws_k<<<1, 64, 0, s>>>(slot, ws, kNormBlocks, 1, 1);
+  AO_KERNEL_CHECK();
+}
+
+template <typename T>
+__global__ void tensor_scale_k(T* X, int64_t n, double alpha) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    X[i] = (T)((double)X[i] * alpha);
+}
+void tensor_scale(void* X, int prec, int64_t n, double alpha, hipStream_t s) {
+  if (prec == AOADMM_PREC_F32) tensor_scale_k<float><<<4096, 256, 0, s>>>((float*)X, n, alpha);
+  else tensor_scale_k<double><<<4096, 256, 0, s>>>((double*)X, n, alpha);
+  AO_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// counter-based generator: splitmix64 finaliser of (seed, stream, index)
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ double u01(uint64_t seed, uint64_t stream, uint64_t idx) {
+  const uint64_t h = mix64(mix64(seed ^ (stream * 0xD1B54A32D192ED03ull)) + idx);
+  return (double)(h >> 11) * (1.0 / 9007199254740992.0);    // [0,1)
+}
+__device__ __forceinline__ double gauss01(uint64_t seed, uint64_t idx) {
+  const double u1 = 1.0 - u01(seed, 101, idx);               // (0,1]
+  const double u2 = u01(seed, 102, idx);
+  return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+
+__global__ void fill_uniform_k(double* x, int64_t n, uint64_t seed, uint64_t stream) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = u01(seed, stream, (uint64_t)i);
+}
+void fill_uniform(double* x, int64_t n, uint64_t seed, hipStream_t s) {
+  int64_t blocks = cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) return;
+  fill_uniform_k<<<(unsigned)blocks, 256, 0, s>>>(x, n, seed, 7);
+  AO_KERNEL_CHECK();
+}
+void synth_factors(double* A, double* B, double* C, const SynthArgs& a, hipStream_t s) {
+  fill_uniform_k<<<256, 256, 0, s>>>(A, a.I_full * a.R, a.seed, 1);
+  fill_uniform_k<<<256, 256, 0, s>>>(B, a.J * a.R, a.seed, 2);
+  fill_uniform_k<<<256, 256, 0, s>>>(C, a.K * a.R, a.seed, 3);
+  AO_KERNEL_CHECK();
+}
+
+static constexpr int kSynthBlocks = 4096;
+size_t synth_ws_bytes() { return (size_t)kSynthBlocks * 3 * sizeof(double); }
+
+// one (j,k) fibre per block iteration; threads sweep the local rows
+template <int PASS, typename T>
+__global__ void synth_k(T* X, double* ws, const double* A, const double* B, const double* C, SynthArgs a,
+                        double sigma, double inv_norm) {
+  __shared__ double bc[kMaxRank];
+  __shared__ double sh[256];
+  double s_cc = 0, s_nn = 0, s_cn = 0;
+  const int64_t ncol = a.J * a.K;
+  for (int64_t col = blockIdx.x; col < ncol; col += gridDim.x) {
+    const int64_t j = col % a.J, k = col / a.J;
+    __syncthreads();
+    if ((int)threadIdx.x < a.R) bc[threadIdx.x] = B[j + a.J * threadIdx.x] * C[k + a.K * threadIdx.x];
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < a.I_pad; i += blockDim.x) {
+      double clean = 0.0, nz = 0.0;
+      if (i < a.I_loc) {
+        const int64_t ig = i + a.row0;
+        for (int r = 0; r < a.R; ++r) clean += A[ig + a.I_full * r] * bc[r];
+        nz = gauss01(a.seed, (uint64_t)(ig + a.I_full * col));
+      }
+      if (PASS == 1) {
+        s_cc += clean * clean; s_nn += nz * nz; s_cn += clean * nz;
+      } else {
+        X[i + a.I_pad * col] = (T)((clean + sigma * nz) * inv_norm);
+      }
+    }
+  }
+  if (PASS == 1) {
+    const double t0 = block_reduce256(s_cc, sh);
+    const double t1 = block_reduce256(s_nn, sh);
+    const double t2 = block_reduce256(s_cn, sh);
+    if (threadIdx.x == 0) {
+      ws[(int64_t)blockIdx.x * 3 + 0] = t0;
+      ws[(int64_t)blockIdx.x * 3 + 1] = t1;
+      ws[(int64_t)blockIdx.x * 3 + 2] = t2;
+    }
+  }
+}
+// out3 = { sum clean^2, sum noise^2, sum clean*noise } over the local block
+void synth_norms(double* out3, const double* A, const double* B, const double* C, const SynthArgs& a,
+                 double* ws, hipStream_t s) {
+  synth_k<1, double><<<kSynthBlocks, 256, 0, s>>>(nullptr, ws, A, B, C, a, 0.0, 1.0);
+  AO_KERNEL_CHECK();
+  sum_ws_k<<<1, 64, 0, s>>>(out3, ws, kSynthBlocks, 3, 3);
+  AO_KERNEL_CHECK();
+}
+void synth_write(void* X, int prec, const double* A, const double* B, const double* C, const SynthArgs& a,
+                  double sigma, double inv_norm, hipStream_t s) {
+  if (prec == AOADMM_PREC_F32)
+    synth_k<2, float><<<kSynthBlocks * 4, 256, 0, s>>>((float*)X, nullptr, A, B, C, a, sigma, inv_norm);
+  else
+    synth_k<2, double><<<kSynthBlocks * 4, 256, 0, s>>>((double*)X, nullptr, A, B, C, a, sigma, inv_norm);
+  AO_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// regulariser values: constraints_to_prox.m:49,53,57,61,77,81
+__global__ void reg_value_k(double* slot, int type, double eta, const double* X, int64_t rows, int R) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  const int64_t n = rows * R;
+  if (type == AOADMM_C_L2_REG) {
+    double tot = 0.0;
+    for (int r = 0; r < R; ++r) {
+      double a = 0.0;
+      for (int64_t i = threadIdx.x; i < rows; i += blockDim.x) { const double v = X[i + rows * r]; a += v * v; }
+      tot += sqrt(block_reduce256(a, sh));
+    }
+    if (threadIdx.x == 0) slot[0] = eta * tot;
+    return;
+  }
+  for (int64_t e = threadIdx.x; e < n; e += blockDim.x) {
+    const double v = X[e];
+    const int64_t i = e % rows;
+    switch (type) {
+      case AOADMM_C_L1_REG: acc += fabs(v); break;
+      case AOADMM_C_L0_REG: acc += (v != 0.0) ? 1.0 : 0.0; break;
+      case AOADMM_C_RIDGE: acc += v * v; break;
+      case AOADMM_C_TV: if (i + 1 < rows) acc += X[e + 1] - v; break;            // no abs(): quirk of :81
+      case AOADMM_C_GL_SMOOTH: if (i + 1 < rows) { const double d = X[e + 1] - v; acc += d * d; } break;
+      default: break;
+    }
+  }
+  const double t = block_reduce256(acc, sh);
+  if (threadIdx.x == 0) slot[0] = eta * t;
+}
+void reg_value(double* slot, int type, double p0, const double* X, int64_t rows, int R, double* ws,
+               hipStream_t s) {
+  (void)ws;
+  reg_value_k<<<1, 256, 0, s>>>(slot, type, p0, X, rows, R);
+  AO_KERNEL_CHECK();
+}
+
+}  // namespace aoadmm

@@ -1,0 +1,173 @@
+// Host-side engine: model (struct Z), state (struct G) and the AO-ADMM outer loop
+// (functions/cmtf_fun_AOADMM.m:87-476) driving the HIP kernels.  Everything stays
+// resident in HBM; the host synchronises once per outer iteration to read the
+// objective values and the inner-iteration counters.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "admm.h"
+#include "common.h"
+#include "contract.h"
+#include "misc.h"
+#include "small.h"
+
+typedef struct ncclComm* ncclComm_t;
+
+namespace aoadmm {
+
+struct FactorRef {
+  const double* p;    // device, column-major
+  int64_t ld;
+  uint64_t version;
+};
+
+// One dense CP block (tensor or matrix) and its partial-contraction cache.
+struct CpBlock {
+  DenseTensor X;       // natural layout, first dimension padded
+  DenseTensor Xt;      // matrices only: transposed copy (second mode contiguous)
+  int nd = 0;
+  int64_t dims[8] = {0};   // local sizes (dims[0] = local rows when sharded)
+  int64_t full0 = 0;       // global size of the first mode
+  int64_t row0 = 0;        // first local row of the first mode
+  bool has_data = false;
+  // dimension-tree cache: T = X x_c F_c, valid while factor c keeps `cached_version`
+  int cached_mode = -1;
+  uint64_t cached_version = 0;
+  ContractPlan plan;
+  DevBuf T, frag, scratch, tmpA, tmpB;
+};
+
+struct ModeInfo {
+  bool defined = false;
+  int64_t rows = 0;
+  int R = 0;
+  bool slabs = false;
+  int K = 0;
+  std::vector<int64_t> rows_k, off_k;
+  int tensor = -1, pos = -1;
+  int coupling = -1;
+  bool constrained = false;
+  ProxSpec prox;
+  DevBuf Lmat, H, H2;
+  int64_t hr = 0, hc = 0, h2r = 0, h2c = 0;
+  double ridge = 0.0;
+  DevBuf fac, Z, mu, muD;
+  bool has_fac = false, has_Z = false, has_mu = false, has_muD = false;
+  int64_t muD_rows = 0, muD_cols = 0;
+  uint64_t version = 1;
+  // work buffers
+  DevBuf A, Ab, gram, C, Bsys, L, rho, Zold, V, Znew, part, proxws, RHS, TD, tmp;
+  const double* Aeff = nullptr;
+};
+
+struct TensorInfo {
+  bool defined = false;
+  bool par2 = false;
+  int nmodes = 0;
+  int modes[8] = {0};
+  double weight = 1.0;
+  CpBlock blk;
+  double normsq = 0.0;
+  bool normsq_valid = false;
+  int last_pos = -1;
+};
+
+struct CouplingInfo {
+  int type = -1;
+  std::vector<int> modes;
+  DevBuf Delta, DeltaOld, BB, AA, LAA, dD, tmp, coef;
+  int64_t rows = 0, cols = 0;
+  bool has_state = false;
+};
+
+struct KernelStats {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double ms = 0.0, bytes = 0.0, flops = 0.0;
+  int64_t launches = 0;
+};
+
+class Engine {
+ public:
+  explicit Engine(int device);
+  ~Engine();
+
+  // model
+  void model_begin(int n_modes, int n_tensors, int n_couplings);
+  void set_mode(int mode, int64_t rows, int rank);
+  void set_mode_slabs(int mode, int K, const int64_t* rows_k, int rank);
+  void add_cp(int p, int n, const int* modes, double weight);
+  void add_par2(int p, const int* modes3, double weight);
+  void set_constraint(int mode, int type, const double* params, int np, const double* Lmat);
+  void set_coupling(int mode, int coupling, const double* H, int64_t hr, int64_t hc, const double* H2,
+                    int64_t h2r, int64_t h2c);
+  void set_coupling_type(int coupling, int type);
+  void set_ridge(const double* ridge);
+  void model_end();
+
+  // data
+  void tensor_upload(int p, const double* data, int prec, int64_t row0, int64_t local_rows);
+  void tensor_synth(int p, int rank, uint64_t seed, double noise, int prec);
+  double tensor_normsq(int p);
+
+  // state
+  void state_set(int field, int index, int slab, const double* host, int64_t rows, int64_t cols);
+  void state_get(int field, int index, int slab, double* host, int64_t rows, int64_t cols);
+
+  // solve
+  void solve(const aoadmm_options& opt, aoadmm_result* out);
+  void resident_mttkrp(int p, int pos, double* out_host, float* ms);
+  void kernel_stats(int reset, double* ms, int64_t* launches, double* bytes, double* flops);
+
+  // communicator
+  void comm_init(const char id[128], int rank, int world);
+  int rank() const { return rank_; }
+  int world() const { return world_; }
+
+  hipStream_t stream() const { return stream_; }
+  int device() const { return device_; }
+
+  // MTTKRP of a dense block against factors (device), result scale*mttkrp into out (ld = ldOut)
+  void block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
+                    int64_t ldOut, bool use_cache, const int* update_seq, int nseq);
+  void block_upload(CpBlock& b, int nd, const int64_t* dims, const double* host, int prec, int64_t row0,
+                    int64_t local_rows);
+  void allreduce(double* buf, int64_t n);
+  double* scratch_slots() { return slots_.d(); }
+  double* red_ws() { return redws_.d(); }
+
+ private:
+  void check_mode(int m) const;
+  void compute_gram(ModeInfo& mi);
+  void update_uncoupled_cp_mode(int m, const aoadmm_options& opt);
+  void prepare_mode_system(int m, int nrho, const aoadmm_options& opt);
+  void coupled_admm(int c, const aoadmm_options& opt);
+  void eval_objective_enqueue(bool first);
+  void ensure_mode_work(ModeInfo& mi);
+  std::vector<int> update_sequence(int p) const;
+
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  int n_modes_ = 0, n_tensors_ = 0, n_couplings_ = 0;
+  bool model_done_ = false;
+  bool has_ridge_ = false;
+  std::vector<ModeInfo> modes_;
+  std::vector<TensorInfo> tensors_;
+  std::vector<CouplingInfo> couplings_;
+  DevBuf ctls_;          // AdmmCtl[n_modes + n_couplings]
+  DevBuf slots_;         // objective scalars
+  DevBuf redws_;         // reduction workspace
+  DevBuf atbws_;
+  DevBuf staging_;
+  KernelStats kstats_;
+  bool profile_ = true;
+  ncclComm_t comm_ = nullptr;
+  int rank_ = 0, world_ = 1;
+
+  AdmmCtl* ctl_of_mode(int m) { return ctls_.as<AdmmCtl>() + m; }
+  AdmmCtl* ctl_of_coupling(int c) { return ctls_.as<AdmmCtl>() + n_modes_ + c; }
+  void timed_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
+                      void* frag, double* T);
+};
+
+}  // namespace aoadmm

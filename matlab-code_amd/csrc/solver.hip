@@ -1,0 +1,992 @@
+// Engine implementation: see solver.h.  Reference control flow:
+// functions/cmtf_fun_AOADMM.m:87-476 (outer loop), :625-695 / :904-983 (coupled ADMM
+// cases 0 and 4), :1213-1363 (objective), functions/evaluate_stopping_conditions.m.
+#include "solver.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <set>
+
+namespace aoadmm {
+
+#define AO_NCCL(expr)                                                                          \
+  do {                                                                                         \
+    ncclResult_t r__ = (expr);                                                                 \
+    if (r__ != ncclSuccess)                                                                    \
+      throw Error(AOADMM_ERR_RCCL, fmt("%s failed: %s", #expr, ncclGetErrorString(r__)));      \
+  } while (0)
+
+static constexpr int kSlotsPerMode = 8;      // objective slots
+static constexpr int kResidPerMode = 8;      // ADMM residual slots
+
+Engine::Engine(int device) : device_(device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw Error(AOADMM_ERR_HIP, "no HIP device available: this library has no CPU fallback");
+  if (device < 0 || device >= n) throw Error(AOADMM_ERR_INVALID, fmt("device %d out of range [0,%d)", device, n));
+  AO_HIP(hipSetDevice(device));
+  AO_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  redws_.alloc(4096 * sizeof(double));
+}
+
+Engine::~Engine() {
+  (void)hipSetDevice(device_);
+  for (auto& pr : kstats_.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  if (comm_) (void)ncclCommDestroy(comm_);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// ---------------------------------------------------------------------------
+// communicator
+// ---------------------------------------------------------------------------
+void Engine::comm_init(const char id[128], int rank, int world) {
+  AO_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world %d/%d", rank, world);
+  AO_HIP(hipSetDevice(device_));
+  if (world > 1) {
+    ncclUniqueId uid;
+    static_assert(sizeof(uid) <= 128, "unique id larger than the ABI buffer");
+    std::memcpy(&uid, id, sizeof(uid));
+    AO_NCCL(ncclCommInitRank(&comm_, world, uid, rank));
+  }
+  rank_ = rank;
+  world_ = world;
+}
+
+void Engine::allreduce(double* buf, int64_t n) {
+  if (world_ <= 1 || n <= 0) return;
+  AO_NCCL(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, comm_, stream_));
+}
+
+// ---------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------
+void Engine::check_mode(int m) const {
+  AO_REQUIRE(m >= 0 && m < n_modes_, "mode %d out of range [0,%d)", m, n_modes_);
+}
+
+void Engine::model_begin(int n_modes, int n_tensors, int n_couplings) {
+  AO_REQUIRE(n_modes > 0 && n_tensors > 0 && n_couplings >= 0, "model_begin: bad counts");
+  AO_HIP(hipSetDevice(device_));
+  n_modes_ = n_modes; n_tensors_ = n_tensors; n_couplings_ = n_couplings;
+  modes_.clear(); tensors_.clear(); couplings_.clear();
+  modes_.resize(n_modes); tensors_.resize(n_tensors); couplings_.resize(n_couplings);
+  model_done_ = false;
+  has_ridge_ = false;
+}
+
+void Engine::set_mode(int mode, int64_t rows, int rank) {
+  check_mode(mode);
+  AO_REQUIRE(rows > 0 && rank > 0 && rank <= kMaxRank, "mode %d: rows=%lld rank=%d invalid (rank <= %d)", mode,
+             (long long)rows, rank, kMaxRank);
+  ModeInfo& mi = modes_[mode];
+  mi.defined = true; mi.rows = rows; mi.R = rank; mi.slabs = false;
+}
+
+void Engine::set_mode_slabs(int mode, int K, const int64_t* rows_k, int rank) {
+  check_mode(mode);
+  AO_REQUIRE(K > 0 && rank > 0 && rank <= kMaxRank, "slab mode %d: bad K/rank", mode);
+  ModeInfo& mi = modes_[mode];
+  mi.defined = true; mi.slabs = true; mi.K = K; mi.R = rank;
+  mi.rows_k.assign(rows_k, rows_k + K);
+  mi.off_k.assign(K + 1, 0);
+  for (int k = 0; k < K; ++k) {
+    AO_REQUIRE(rows_k[k] > 0, "slab %d has no rows", k);
+    mi.off_k[k + 1] = mi.off_k[k] + rows_k[k];
+  }
+  mi.rows = mi.off_k[K];
+}
+
+void Engine::add_cp(int p, int n, const int* modes, double weight) {
+  AO_REQUIRE(p >= 0 && p < n_tensors_, "tensor %d out of range", p);
+  AO_REQUIRE(n >= 2 && n <= 8, "CP block needs 2..8 modes");
+  TensorInfo& t = tensors_[p];
+  t.defined = true; t.par2 = false; t.nmodes = n; t.weight = weight;
+  for (int i = 0; i < n; ++i) {
+    check_mode(modes[i]);
+    AO_REQUIRE(modes_[modes[i]].defined && !modes_[modes[i]].slabs, "mode %d undefined or slab-valued", modes[i]);
+    AO_REQUIRE(modes_[modes[i]].tensor < 0, "mode %d already belongs to tensor %d", modes[i], modes_[modes[i]].tensor);
+    t.modes[i] = modes[i];
+    modes_[modes[i]].tensor = p;
+    modes_[modes[i]].pos = i;
+    AO_REQUIRE(modes_[modes[i]].R == modes_[modes[0]].R, "modes of tensor %d disagree on the rank", p);
+  }
+}
+
+void Engine::add_par2(int p, const int* modes3, double weight) {
+  (void)p; (void)modes3; (void)weight;
+  throw Error(AOADMM_ERR_UNSUPPORTED, "PARAFAC2 blocks are not in the device path yet (use the MATLAB path)");
+}
+
+void Engine::set_constraint(int mode, int type, const double* params, int np, const double* Lmat) {
+  check_mode(mode);
+  ModeInfo& mi = modes_[mode];
+  AO_REQUIRE(type >= AOADMM_C_NONE && type <= AOADMM_C_TPARAFAC2, "unknown constraint id %d", type);
+  mi.constrained = type != AOADMM_C_NONE;
+  mi.prox = ProxSpec();
+  mi.prox.type = type;
+  if (np > 0) mi.prox.p0 = params[0];
+  if (np > 1) mi.prox.p1 = params[1];
+  auto need = [&](int n) { AO_REQUIRE(np >= n, "constraint %d on mode %d needs %d parameter(s)", type, mode, n); };
+  switch (type) {
+    case AOADMM_C_BOX: need(2); break;
+    case AOADMM_C_SIMPLEX_COL: case AOADMM_C_SIMPLEX_ROW: case AOADMM_C_UNIMODAL: case AOADMM_C_L1_BALL:
+    case AOADMM_C_L2_BALL: case AOADMM_C_NONNEG_L2_BALL: case AOADMM_C_L1_REG: case AOADMM_C_L0_REG:
+    case AOADMM_C_L2_REG: case AOADMM_C_RIDGE: case AOADMM_C_GL_SMOOTH: case AOADMM_C_TV: need(1); break;
+    case AOADMM_C_QUADRATIC: case AOADMM_C_TPARAFAC2:
+      throw Error(AOADMM_ERR_UNSUPPORTED, fmt("constraint id %d has no device prox yet (route to the MATLAB path)", type));
+    default: break;
+  }
+  (void)Lmat;
+}
+
+static void upload_small(DevBuf& b, const double* host, int64_t n, hipStream_t s) {
+  b.ensure((size_t)n * sizeof(double));
+  AO_HIP(hipMemcpyAsync(b.p, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+  AO_HIP(hipStreamSynchronize(s));
+}
+
+void Engine::set_coupling(int mode, int coupling, const double* H, int64_t hr, int64_t hc, const double* H2,
+                          int64_t h2r, int64_t h2c) {
+  check_mode(mode);
+  AO_REQUIRE(coupling >= -1 && coupling < n_couplings_, "coupling id %d out of range", coupling);
+  ModeInfo& mi = modes_[mode];
+  mi.coupling = coupling;
+  mi.hr = mi.hc = mi.h2r = mi.h2c = 0;
+  if (H && hr > 0 && hc > 0) { upload_small(mi.H, H, hr * hc, stream_); mi.hr = hr; mi.hc = hc; }
+  if (H2 && h2r > 0 && h2c > 0) { upload_small(mi.H2, H2, h2r * h2c, stream_); mi.h2r = h2r; mi.h2c = h2c; }
+}
+
+void Engine::set_coupling_type(int coupling, int type) {
+  AO_REQUIRE(coupling >= 0 && coupling < n_couplings_, "coupling id %d out of range", coupling);
+  AO_REQUIRE(type >= 0 && type <= 5, "coupling type %d invalid", type);
+  couplings_[coupling].type = type;
+}
+
+void Engine::set_ridge(const double* ridge) {
+  has_ridge_ = ridge != nullptr;
+  for (int m = 0; m < n_modes_; ++m) modes_[m].ridge = ridge ? ridge[m] : 0.0;
+}
+
+void Engine::model_end() {
+  for (int m = 0; m < n_modes_; ++m) {
+    AO_REQUIRE(modes_[m].defined, "mode %d has no size", m);
+    AO_REQUIRE(modes_[m].tensor >= 0, "mode %d belongs to no tensor (Mismatch between size and modes inputs)", m);
+  }
+  for (int p = 0; p < n_tensors_; ++p) AO_REQUIRE(tensors_[p].defined, "tensor %d undefined", p);
+  for (int c = 0; c < n_couplings_; ++c) {
+    CouplingInfo& ci = couplings_[c];
+    AO_REQUIRE(ci.type >= 0, "coupling %d has no type (Mismatch between number of couplings and coupling types)", c);
+    ci.modes.clear();
+    for (int m = 0; m < n_modes_; ++m)
+      if (modes_[m].coupling == c) ci.modes.push_back(m);
+    AO_REQUIRE(!ci.modes.empty(), "coupling %d couples no mode", c);
+    AO_REQUIRE(ci.modes.size() <= 8, "more than 8 modes in one coupling");
+    const ModeInfo& m0 = modes_[ci.modes[0]];
+    if (ci.type == 0) {                       // check_data_input.m:48-61
+      ci.rows = m0.rows; ci.cols = m0.R;
+      for (int m : ci.modes) {
+        AO_REQUIRE(modes_[m].rows == m0.rows, "Coupled factor matrices of mode %d and mode %d need to have same number of rows.", ci.modes[0] + 1, m + 1);
+        AO_REQUIRE(modes_[m].R == m0.R, "Coupled factor matrices of mode %d and mode %d need to have same number of components/columns.", ci.modes[0] + 1, m + 1);
+      }
+    } else if (ci.type == 4) {                // C = Delta*H : H is (cols x R_m)
+      AO_REQUIRE(m0.hr > 0, "Coupling matrix for mode %d is missing.", ci.modes[0] + 1);
+      ci.rows = m0.rows; ci.cols = m0.hr;
+      for (int m : ci.modes) {
+        AO_REQUIRE(modes_[m].hr > 0, "Coupling matrix for mode %d is missing.", m + 1);
+        AO_REQUIRE(modes_[m].rows == ci.rows && modes_[m].hr == ci.cols && modes_[m].hc == modes_[m].R,
+                   "coupling type 4: transformation matrix of mode %d has the wrong shape", m + 1);
+      }
+    } else {
+      throw Error(AOADMM_ERR_UNSUPPORTED, fmt("coupling type %d is not in the device path yet (use the MATLAB path)", ci.type));
+    }
+  }
+  ctls_.alloc((size_t)(n_modes_ + n_couplings_ + 1) * sizeof(AdmmCtl));
+  AO_HIP(hipMemsetAsync(ctls_.p, 0, ctls_.bytes, stream_));
+  slots_.alloc((size_t)(n_modes_ * (kSlotsPerMode + kResidPerMode) + 2 * n_tensors_ + 16) * sizeof(double));
+  AO_HIP(hipMemsetAsync(slots_.p, 0, slots_.bytes, stream_));
+  AO_HIP(hipStreamSynchronize(stream_));
+  model_done_ = true;
+}
+
+// ---------------------------------------------------------------------------
+// data
+// ---------------------------------------------------------------------------
+static int64_t pad_of(int prec, int64_t n) { return round_up(n, prec == AOADMM_PREC_F32 ? 4 : 2); }
+
+void Engine::block_upload(CpBlock& b, int nd, const int64_t* dims, const double* host, int prec, int64_t row0,
+                          int64_t local_rows) {
+  AO_REQUIRE(nd >= 2 && nd <= 8, "tensor order %d unsupported", nd);
+  AO_REQUIRE(prec == AOADMM_PREC_F64 || prec == AOADMM_PREC_F32, "bad precision id %d", prec);
+  AO_REQUIRE(row0 >= 0 && local_rows > 0 && row0 + local_rows <= dims[0], "bad row block [%lld,+%lld) of %lld",
+             (long long)row0, (long long)local_rows, (long long)dims[0]);
+  AO_HIP(hipSetDevice(device_));
+  b.nd = nd;
+  b.full0 = dims[0];
+  b.row0 = row0;
+  b.dims[0] = local_rows;
+  int64_t ncols = 1;
+  for (int i = 1; i < nd; ++i) { b.dims[i] = dims[i]; ncols *= dims[i]; }
+  b.X.prec = prec; b.X.nd = nd;
+  for (int i = 0; i < nd; ++i) b.X.dims[i] = b.dims[i];
+  b.X.pad0 = pad_of(prec, local_rows);
+  b.X.data.alloc((size_t)b.X.elems_padded() * b.X.elem_size());
+  // host block layout: local_rows x ncols column-major (the caller extracted its rows)
+  const int64_t chunk_cols = std::max<int64_t>(1, (int64_t)(64ll << 20) / local_rows);   // ~512 MB of doubles
+  staging_.ensure((size_t)std::min(chunk_cols, ncols) * local_rows * sizeof(double));
+  for (int64_t c0 = 0; c0 < ncols; c0 += chunk_cols) {
+    const int64_t nc = std::min(chunk_cols, ncols - c0);
+    AO_HIP(hipMemcpyAsync(staging_.p, host + c0 * local_rows, (size_t)nc * local_rows * sizeof(double),
+                          hipMemcpyHostToDevice, stream_));
+    pad_convert(b.X.data.p, prec, b.X.pad0, staging_.d(), local_rows, nc, c0, stream_);
+    AO_HIP(hipStreamSynchronize(stream_));
+  }
+  if (nd == 2) {
+    // transposed copy for the second mode (matrices are small next to tensors)
+    b.Xt.prec = prec; b.Xt.nd = 2;
+    b.Xt.dims[0] = dims[1]; b.Xt.dims[1] = local_rows;
+    b.Xt.pad0 = pad_of(prec, dims[1]);
+    b.Xt.data.alloc((size_t)b.Xt.pad0 * local_rows * b.Xt.elem_size());
+    AO_REQUIRE(ncols * local_rows <= (int64_t)(1ll << 28), "matrix block too large for the transposed copy");
+    staging_.ensure((size_t)ncols * local_rows * sizeof(double));
+    AO_HIP(hipMemcpyAsync(staging_.p, host, (size_t)ncols * local_rows * sizeof(double), hipMemcpyHostToDevice, stream_));
+    transpose_convert(b.Xt.data.p, prec, b.Xt.pad0, staging_.d(), local_rows, ncols, stream_);
+    AO_HIP(hipStreamSynchronize(stream_));
+  }
+  b.has_data = true;
+  b.cached_mode = -1;
+}
+
+void Engine::tensor_upload(int p, const double* data, int prec, int64_t row0, int64_t local_rows) {
+  AO_REQUIRE(model_done_, "call aoadmm_model_end first");
+  AO_REQUIRE(p >= 0 && p < n_tensors_, "tensor %d out of range", p);
+  TensorInfo& t = tensors_[p];
+  AO_REQUIRE(!t.par2, "tensor %d is PARAFAC2: use aoadmm_par2_slab_upload", p);
+  int64_t dims[8];
+  for (int i = 0; i < t.nmodes; ++i) dims[i] = modes_[t.modes[i]].rows;
+  if (local_rows < 0) {            // full array given: every rank keeps its block of rows
+    int64_t I = dims[0];
+    int64_t per = cdiv(I, world_);
+    row0 = std::min<int64_t>(I, per * rank_);
+    local_rows = std::min<int64_t>(I, row0 + per) - row0;
+    AO_REQUIRE(local_rows > 0, "rank %d owns no rows of tensor %d (first mode %lld rows, %d ranks)", rank_, p, (long long)I, world_);
+    if (world_ == 1) {
+      block_upload(t.blk, t.nmodes, dims, data, prec, 0, I);
+    } else {
+      int64_t ncols = 1;
+      for (int i = 1; i < t.nmodes; ++i) ncols *= dims[i];
+      std::vector<double> blk((size_t)local_rows * ncols);
+      for (int64_t c = 0; c < ncols; ++c)
+        std::memcpy(&blk[(size_t)c * local_rows], data + c * I + row0, (size_t)local_rows * sizeof(double));
+      block_upload(t.blk, t.nmodes, dims, blk.data(), prec, row0, local_rows);
+    }
+  } else {
+    block_upload(t.blk, t.nmodes, dims, data, prec, row0, local_rows);
+  }
+  t.normsq_valid = false;
+}
+
+double Engine::tensor_normsq(int p) {
+  AO_REQUIRE(p >= 0 && p < n_tensors_, "tensor %d out of range", p);
+  TensorInfo& t = tensors_[p];
+  AO_REQUIRE(t.blk.has_data, "tensor %d has no data", p);
+  if (!t.normsq_valid) {
+    AO_HIP(hipSetDevice(device_));
+    DevBuf ws;
+    ws.alloc(1024 * sizeof(double) + 64);
+    double* slot = slots_.d() + n_modes_ * (kSlotsPerMode + kResidPerMode) + 2 * n_tensors_;
+    tensor_sumsq(slot, t.blk.X.data.p, t.blk.X.prec, t.blk.X.elems_padded(), ws.d(), stream_);
+    allreduce(slot, 1);
+    double v = 0;
+    AO_HIP(hipMemcpyAsync(&v, slot, sizeof(double), hipMemcpyDeviceToHost, stream_));
+    AO_HIP(hipStreamSynchronize(stream_));
+    t.normsq = v;
+    t.normsq_valid = true;
+  }
+  return t.normsq;
+}
+
+void Engine::tensor_synth(int p, int rank, uint64_t seed, double noise, int prec) {
+  AO_REQUIRE(model_done_, "call aoadmm_model_end first");
+  AO_REQUIRE(p >= 0 && p < n_tensors_, "tensor %d out of range", p);
+  TensorInfo& t = tensors_[p];
+  AO_REQUIRE(!t.par2 && t.nmodes == 3, "synthetic generator handles 3-way CP blocks");
+  AO_REQUIRE(rank > 0 && rank <= kMaxRank, "bad rank");
+  AO_HIP(hipSetDevice(device_));
+  const int64_t I = modes_[t.modes[0]].rows, J = modes_[t.modes[1]].rows, K = modes_[t.modes[2]].rows;
+  const int64_t per = cdiv(I, world_);
+  const int64_t row0 = std::min<int64_t>(I, per * rank_);
+  const int64_t loc = std::min<int64_t>(I, row0 + per) - row0;
+  AO_REQUIRE(loc > 0, "rank %d owns no rows", rank_);
+  CpBlock& b = t.blk;
+  b.nd = 3; b.full0 = I; b.row0 = row0;
+  b.dims[0] = loc; b.dims[1] = J; b.dims[2] = K;
+  b.X.prec = prec; b.X.nd = 3;
+  b.X.dims[0] = loc; b.X.dims[1] = J; b.X.dims[2] = K;
+  b.X.pad0 = pad_of(prec, loc);
+  b.X.data.alloc((size_t)b.X.elems_padded() * b.X.elem_size());
+  DevBuf A, B, C, ws;
+  A.alloc((size_t)I * rank * 8); B.alloc((size_t)J * rank * 8); C.alloc((size_t)K * rank * 8);
+  ws.alloc(synth_ws_bytes());
+  SynthArgs a;
+  a.I_loc = loc; a.I_pad = b.X.pad0; a.J = J; a.K = K; a.row0 = row0; a.I_full = I; a.R = rank; a.seed = seed;
+  synth_factors(A.d(), B.d(), C.d(), a, stream_);
+  double* slot = slots_.d() + n_modes_ * (kSlotsPerMode + kResidPerMode) + 2 * n_tensors_;
+  synth_norms(slot, A.d(), B.d(), C.d(), a, ws.d(), stream_);
+  allreduce(slot, 3);
+  double h[3];
+  AO_HIP(hipMemcpyAsync(h, slot, 3 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  AO_HIP(hipStreamSynchronize(stream_));
+  // sigma = noise*||X0||/||N|| (create_coupled_data.m:158-162), then X <- X/||X|| (example_script1:91-92)
+  const double sigma = h[1] > 0 ? noise * std::sqrt(h[0]) / std::sqrt(h[1]) : 0.0;
+  const double nsq = h[0] + 2.0 * sigma * h[2] + sigma * sigma * h[1];
+  synth_write(b.X.data.p, prec, A.d(), B.d(), C.d(), a, sigma, 1.0 / std::sqrt(nsq), stream_);
+  AO_HIP(hipStreamSynchronize(stream_));
+  b.has_data = true;
+  b.cached_mode = -1;
+  t.normsq_valid = false;
+}
+
+// ---------------------------------------------------------------------------
+// state
+// ---------------------------------------------------------------------------
+void Engine::state_set(int field, int index, int slab, const double* host, int64_t rows, int64_t cols) {
+  AO_REQUIRE(model_done_, "call aoadmm_model_end first");
+  AO_REQUIRE(host != nullptr && rows > 0 && cols > 0, "state_set: empty array");
+  AO_HIP(hipSetDevice(device_));
+  (void)slab;
+  auto put = [&](DevBuf& b) {
+    b.ensure((size_t)rows * cols * sizeof(double));
+    AO_HIP(hipMemcpyAsync(b.p, host, (size_t)rows * cols * sizeof(double), hipMemcpyHostToDevice, stream_));
+    AO_HIP(hipStreamSynchronize(stream_));
+  };
+  if (field == AOADMM_F_COUPLING_FAC) {
+    AO_REQUIRE(index >= 0 && index < n_couplings_, "coupling %d out of range", index);
+    CouplingInfo& ci = couplings_[index];
+    AO_REQUIRE(rows == ci.rows && cols == ci.cols, "coupling_fac{%d} must be %lld x %lld", index + 1, (long long)ci.rows, (long long)ci.cols);
+    put(ci.Delta);
+    ci.has_state = true;
+    return;
+  }
+  if (field == AOADMM_F_DELTAB || field == AOADMM_F_P || field == AOADMM_F_MU_DELTAB)
+    throw Error(AOADMM_ERR_UNSUPPORTED, "PARAFAC2 state is not in the device path yet");
+  check_mode(index);
+  ModeInfo& mi = modes_[index];
+  AO_REQUIRE(!mi.slabs, "slab-valued mode state is not in the device path yet");
+  switch (field) {
+    case AOADMM_F_FAC:
+      AO_REQUIRE(rows == mi.rows && cols == mi.R, "fac{%d} must be %lld x %d", index + 1, (long long)mi.rows, mi.R);
+      put(mi.fac); mi.has_fac = true; mi.version++;
+      break;
+    case AOADMM_F_CONSTRAINT_FAC:
+      AO_REQUIRE(rows == mi.rows && cols == mi.R, "constraint_fac{%d} has the wrong size", index + 1);
+      put(mi.Z); mi.has_Z = true;
+      break;
+    case AOADMM_F_CONSTRAINT_DUAL:
+      AO_REQUIRE(rows == mi.rows && cols == mi.R, "constraint_dual_fac{%d} has the wrong size", index + 1);
+      put(mi.mu); mi.has_mu = true;
+      break;
+    case AOADMM_F_COUPLING_DUAL:
+      put(mi.muD); mi.has_muD = true; mi.muD_rows = rows; mi.muD_cols = cols;
+      break;
+    default: throw Error(AOADMM_ERR_INVALID, fmt("unknown state field %d", field));
+  }
+}
+
+void Engine::state_get(int field, int index, int slab, double* host, int64_t rows, int64_t cols) {
+  AO_REQUIRE(host != nullptr, "state_get: null destination");
+  AO_HIP(hipSetDevice(device_));
+  (void)slab;
+  const DevBuf* src = nullptr;
+  int64_t r = 0, c = 0;
+  if (field == AOADMM_F_COUPLING_FAC) {
+    AO_REQUIRE(index >= 0 && index < n_couplings_, "coupling %d out of range", index);
+    src = &couplings_[index].Delta; r = couplings_[index].rows; c = couplings_[index].cols;
+    AO_REQUIRE(couplings_[index].has_state, "coupling_fac{%d} was never set", index + 1);
+  } else {
+    check_mode(index);
+    ModeInfo& mi = modes_[index];
+    r = mi.rows; c = mi.R;
+    switch (field) {
+      case AOADMM_F_FAC: src = &mi.fac; AO_REQUIRE(mi.has_fac, "fac{%d} was never set", index + 1); break;
+      case AOADMM_F_CONSTRAINT_FAC: src = &mi.Z; AO_REQUIRE(mi.has_Z, "constraint_fac{%d} was never set", index + 1); break;
+      case AOADMM_F_CONSTRAINT_DUAL: src = &mi.mu; AO_REQUIRE(mi.has_mu, "constraint_dual_fac{%d} was never set", index + 1); break;
+      case AOADMM_F_COUPLING_DUAL:
+        src = &mi.muD; r = mi.muD_rows; c = mi.muD_cols;
+        AO_REQUIRE(mi.has_muD, "coupling_dual_fac{%d} was never set", index + 1);
+        break;
+      default: throw Error(AOADMM_ERR_UNSUPPORTED, fmt("state field %d not available", field));
+    }
+  }
+  AO_REQUIRE(rows == r && cols == c, "state_get: destination is %lld x %lld, field is %lld x %lld", (long long)rows,
+             (long long)cols, (long long)r, (long long)c);
+  AO_HIP(hipMemcpyAsync(host, src->p, (size_t)r * c * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  AO_HIP(hipStreamSynchronize(stream_));
+}
+
+// ---------------------------------------------------------------------------
+// MTTKRP engine
+// ---------------------------------------------------------------------------
+void Engine::timed_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
+                            void* frag, double* T) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (profile_ && kstats_.pending.size() < 100000) {
+    AO_HIP(hipEventCreate(&e0));
+    AO_HIP(hipEventCreate(&e1));
+    AO_HIP(hipEventRecord(e0, stream_));
+  }
+  launch_contract(X, prec, pl, F, ldF, frag, T, stream_);
+  if (e0) {
+    AO_HIP(hipEventRecord(e1, stream_));
+    kstats_.pending.emplace_back(e0, e1);
+  }
+  kstats_.launches++;
+  kstats_.bytes += pl.algorithmic_bytes(prec);
+  kstats_.flops += pl.flops();
+}
+
+void Engine::kernel_stats(int reset, double* ms, int64_t* launches, double* bytes, double* flops) {
+  AO_HIP(hipSetDevice(device_));
+  AO_HIP(hipStreamSynchronize(stream_));
+  for (auto& pr : kstats_.pending) {
+    float t = 0.f;
+    AO_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
+    kstats_.ms += t;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  kstats_.pending.clear();
+  if (ms) *ms = kstats_.ms;
+  if (launches) *launches = kstats_.launches;
+  if (bytes) *bytes = kstats_.bytes;
+  if (flops) *flops = kstats_.flops;
+  if (reset) { kstats_.ms = 0; kstats_.launches = 0; kstats_.bytes = 0; kstats_.flops = 0; }
+}
+
+// distance (in updates) until tensor position `c` is updated again after position `pos`
+static int next_update_distance(int pos, int c, const int* seq, int n) {
+  if (!seq || n <= 0) return c;            // no information: prefer the last mode
+  int at = -1;
+  for (int i = 0; i < n; ++i)
+    if (seq[i] == pos) at = i;
+  if (at < 0) return c;
+  for (int d = 1; d <= n; ++d)
+    if (seq[(at + d) % n] == c) return d;
+  return n + 1;                              // never updated
+}
+
+void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
+                          int64_t ldOut, bool use_cache, const int* update_seq, int nseq) {
+  AO_REQUIRE(b.has_data, "tensor has no data");
+  AO_REQUIRE(pos >= 0 && pos < b.nd, "mttkrp: mode %d out of range", pos);
+  const int prec = b.X.prec;
+  const int64_t I = b.dims[0], Ip = b.X.pad0;
+  const bool sharded = world_ > 1;
+  double* out_local = out;
+  const int64_t out_rows_full = (pos == 0) ? b.full0 : b.dims[pos];
+  if (sharded && pos == 0) {
+    // every rank fills its own rows of a zeroed buffer; the all-reduce is the all-gather
+    for (int r = 0; r < R; ++r)
+      AO_HIP(hipMemsetAsync(out + ldOut * r, 0, (size_t)out_rows_full * sizeof(double), stream_));
+    out_local = out + b.row0;
+  }
+  const double* F0 = facs[0].p + (sharded ? b.row0 : 0);     // local rows of the first factor
+
+  if (b.nd == 2) {
+    const int64_t J = b.dims[1];
+    if (pos == 0) {
+      ContractPlan pl = make_plan(1, 0, Ip, Ip, J, R, prec);
+      b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
+      timed_contract(b.X.data.p, prec, pl, facs[1].p, facs[1].ld, b.frag.p, b.T.d());
+      launch_t_to_colmajor(b.T.d(), pl.nchunk, pl.trows(), I, R, scale, out_local, ldOut, stream_);
+    } else {
+      const int64_t Jp = b.Xt.pad0;
+      ContractPlan pl = make_plan(1, 0, Jp, Jp, I, R, prec);
+      b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
+      timed_contract(b.Xt.data.p, prec, pl, F0, facs[0].ld, b.frag.p, b.T.d());
+      launch_t_to_colmajor(b.T.d(), pl.nchunk, pl.trows(), J, R, scale, out_local, ldOut, stream_);
+    }
+    b.cached_mode = -1;
+  } else if (b.nd == 3) {
+    const int64_t J = b.dims[1], K = b.dims[2];
+    bool hit = use_cache && b.cached_mode >= 1 && b.cached_mode != pos &&
+               facs[b.cached_mode].version == b.cached_version;
+    if (!hit) {
+      int c;
+      if (pos == 1) c = 2;
+      else if (pos == 2) c = 1;
+      else c = (next_update_distance(pos, 1, update_seq, nseq) > next_update_distance(pos, 2, update_seq, nseq)) ? 1 : 2;
+      ContractPlan pl = (c == 2) ? make_plan(1, 0, Ip * J, Ip * J, K, R, prec)
+                                 : make_plan(K, Ip * J, Ip, Ip, J, R, prec);
+      b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
+      timed_contract(b.X.data.p, prec, pl, facs[c].p, facs[c].ld, b.frag.p, b.T.d());
+      b.cached_mode = c; b.cached_version = facs[c].version; b.plan = pl;
+    }
+    const int c = b.cached_mode;
+    const ContractPlan& pl = b.plan;
+    const int64_t Bn = (c == 2) ? J : K;           // second index of T's rows (i + Ip*b)
+    const int other = (c == 2) ? 1 : 2;            // tensor position of that index
+    if (pos == 0) {
+      b.scratch.ensure(reduce_outer_scratch_bytes(I, Bn, R));
+      launch_reduce_outer(b.T.d(), pl.nchunk, pl.trows(), I, Ip, Bn, R, facs[other].p, facs[other].ld, scale,
+                          out_local, ldOut, b.scratch.d(), stream_);
+    } else {
+      AO_REQUIRE(pos == other, "internal: cached contraction cannot serve this mode");
+      launch_reduce_inner(b.T.d(), pl.nchunk, pl.trows(), I, Ip, Bn, R, F0, facs[0].ld, scale, out_local, ldOut,
+                          stream_);
+    }
+  } else {
+    // N-way (N > 3): contract the last mode (or the one before it when pos is last), then fold the
+    // remaining trailing modes one by one with reduce_outer, finally reduce over the leading modes
+    // against their materialised Khatri-Rao product.
+    throw Error(AOADMM_ERR_UNSUPPORTED, "tensors of order > 3 are not in the device path yet");
+  }
+  if (sharded) {
+    if (ldOut == out_rows_full) allreduce(out, out_rows_full * R);
+    else for (int r = 0; r < R; ++r) allreduce(out + ldOut * r, out_rows_full);
+  }
+}
+
+std::vector<int> Engine::update_sequence(int p) const {
+  // order in which the positions of tensor p are updated inside one outer iteration:
+  // uncoupled modes first, then coupling ids ascending (cmtf_fun_AOADMM.m:10,89-93)
+  std::vector<int> seq;
+  const TensorInfo& t = tensors_[p];
+  for (int cid = -1; cid < n_couplings_; ++cid)
+    for (int i = 0; i < t.nmodes; ++i)
+      if (modes_[t.modes[i]].coupling == cid) seq.push_back(i);
+  return seq;
+}
+
+// ---------------------------------------------------------------------------
+// per-mode pieces of the outer loop
+// ---------------------------------------------------------------------------
+void Engine::ensure_mode_work(ModeInfo& mi) {
+  const size_t nR = (size_t)mi.rows * mi.R * sizeof(double), RR = (size_t)mi.R * mi.R * sizeof(double);
+  mi.A.ensure(nR); mi.Ab.ensure(nR);
+  mi.gram.ensure(RR); mi.C.ensure(RR); mi.Bsys.ensure(RR); mi.L.ensure(RR);
+  mi.rho.ensure(64);
+  mi.Zold.ensure(nR); mi.V.ensure(nR); mi.Znew.ensure(nR); mi.RHS.ensure(nR); mi.TD.ensure(nR); mi.tmp.ensure(nR);
+  mi.part.ensure((size_t)admm_partials(mi.rows) * 4 * sizeof(double) + 64 * 4 * sizeof(double));
+  if (mi.constrained) mi.proxws.ensure(prox_ws_bytes(mi.prox.type, mi.rows, mi.R));
+  atbws_.ensure(atb_ws_bytes(mi.rows, mi.R, mi.R));
+}
+
+void Engine::compute_gram(ModeInfo& mi) {
+  atb_small(mi.gram.d(), mi.fac.d(), mi.rows, mi.fac.d(), mi.rows, mi.rows, mi.R, mi.R, atbws_.d(), nullptr, stream_);
+}
+
+void Engine::prepare_mode_system(int m, int nrho, const aoadmm_options& opt) {
+  ModeInfo& mi = modes_[m];
+  TensorInfo& t = tensors_[mi.tensor];
+  FactorRef facs[8];
+  for (int i = 0; i < t.nmodes; ++i) {
+    const ModeInfo& o = modes_[t.modes[i]];
+    facs[i] = FactorRef{o.fac.d(), o.rows, o.version};
+  }
+  std::vector<int> seq = update_sequence(mi.tensor);
+  block_mttkrp(t.blk, mi.pos, facs, mi.R, t.weight, mi.A.d(), mi.rows, opt.use_dimtree != 0, seq.data(), (int)seq.size());
+  SysBuild sb;
+  sb.ngram = 0;
+  for (int i = 0; i < t.nmodes; ++i)
+    if (i != mi.pos) sb.grams[sb.ngram++] = modes_[t.modes[i]].gram.d();     // :98-103, :109,:112
+  sb.Cpre = nullptr;
+  sb.w = t.weight;
+  sb.ridge = has_ridge_ ? mi.ridge : 0.0;
+  sb.bsum_half = opt.bsum ? opt.bsum_weight / 2 : 0.0;
+  sb.rho_scale = 1.0;
+  sb.nrho = nrho;
+  sb.R = mi.R;
+  sb.C = mi.C.d(); sb.rho = mi.rho.d(); sb.Bsys = mi.Bsys.d(); sb.L = mi.L.d();
+  sb.ctl = ctl_of_mode(m);
+  sys_build(sb, stream_);
+  t.last_pos = mi.pos;                                                        // :121-123
+  mi.Aeff = mi.A.d();
+  if (opt.bsum) {                                                             // :124-127
+    Coef c[2] = {coef(1.0), coef(opt.bsum_weight / 2)};
+    const double* x[2] = {mi.A.d(), mi.fac.d()};
+    ew_lincomb(mi.Ab.d(), mi.rows * mi.R, 2, c, x, nullptr, stream_);
+    mi.Aeff = mi.Ab.d();
+  }
+}
+
+void Engine::update_uncoupled_cp_mode(int m, const aoadmm_options& opt) {
+  ModeInfo& mi = modes_[m];
+  prepare_mode_system(m, mi.constrained ? 1 : 0, opt);
+  AdmmCtl* ctl = ctl_of_mode(m);
+  if (!mi.constrained) {
+    // G.fac{m} = A{m}/B{m}  (:134): B is symmetric positive definite -> Cholesky solve
+    row_solve(mi.fac.d(), mi.rows, mi.Aeff, mi.rows, mi.L.d(), mi.rows, mi.R, nullptr, stream_);
+  } else {
+    AdmmMode am;
+    am.A = mi.Aeff; am.L = mi.L.d(); am.rho = mi.rho.d();
+    am.fac = mi.fac.d(); am.Z = mi.Z.d(); am.mu = mi.mu.d();
+    am.rows = mi.rows; am.R = mi.R; am.prox = mi.prox;
+    for (int it = 0; it < opt.MaxInnerIters; ++it)
+      admm_constrained_iteration(am, mi.part.d(), mi.V.d(), mi.Znew.d(), mi.proxws.d(), ctl, opt.MaxInnerIters,
+                                 opt.innerRelPrTol_constr, opt.innerRelDualTol_constr, stream_);
+  }
+  compute_gram(mi);                                                           // :148
+  mi.version++;
+}
+
+// T(Delta) for mode m: Delta (type 0) or Delta*H_m (type 4) into `dst`
+static void coupling_image(double* dst, const CouplingInfo& ci, const double* Delta, const ModeInfo& mi,
+                           const AdmmCtl* ctl, hipStream_t s) {
+  if (ci.type == 0) {
+    Coef c[1] = {coef(1.0)};
+    const double* x[1] = {Delta};
+    ew_lincomb(dst, ci.rows * ci.cols, 1, c, x, ctl, s);
+  } else {
+    gemm_small(dst, mi.rows, Delta, ci.rows, mi.H.d(), mi.hr, ci.rows, (int)ci.cols, mi.R, 0, coef(1.0), 0.0, ctl, s);
+  }
+}
+
+__global__ void coupling_coefs_k(double* coef, const double* const* rhos, int n) {
+  // coef[j] = rho_j / sum rho  (:661-675)
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += rhos[j][0];
+    for (int j = 0; j < n; ++j) coef[j] = 1.0 / s * rhos[j][0];
+    coef[n] = s;
+  }
+}
+
+struct AAArgs { const double* H[8]; const double* rho[8]; int R[8]; int n; int Rc; };
+__global__ void coupling_AA_k(double* AA, AAArgs a) {
+  // AA = sum_j rho_j * H_j * H_j'   (:941-954)
+  const int Rc = a.Rc;
+  for (int e = threadIdx.x; e < Rc * Rc; e += blockDim.x) {
+    const int i = e % Rc, k = e / Rc;
+    double acc = 0.0;
+    for (int j = 0; j < a.n; ++j) {
+      double t = 0.0;
+      for (int q = 0; q < a.R[j]; ++q) t += a.H[j][i + Rc * q] * a.H[j][k + Rc * q];
+      acc += a.rho[j][0] * t;
+    }
+    AA[e] = acc;
+  }
+}
+
+void Engine::coupled_admm(int c, const aoadmm_options& opt) {
+  CouplingInfo& ci = couplings_[c];
+  AdmmCtl* ctl = ctl_of_coupling(c);
+  const int n = (int)ci.modes.size();
+  const int64_t nD = ci.rows * ci.cols;
+  ci.DeltaOld.ensure(nD * 8); ci.BB.ensure(nD * 8); ci.dD.ensure(nD * 8); ci.tmp.ensure(nD * 8);
+  ci.coef.ensure(64 * 8);
+  ci.AA.ensure((size_t)ci.cols * ci.cols * 8); ci.LAA.ensure((size_t)ci.cols * ci.cols * 8);
+  double* resid = slots_.d() + n_modes_ * kSlotsPerMode + 2 * n_tensors_;
+  // reset the loop control (the per-mode sys_build calls reset their own blocks)
+  ctl_reset(ctl, stream_);
+  // per-outer-iteration constants
+  DevBuf rho_ptrs;
+  std::vector<const double*> hp(n);
+  for (int j = 0; j < n; ++j) hp[j] = modes_[ci.modes[j]].rho.d();
+  rho_ptrs.alloc(n * sizeof(double*));
+  AO_HIP(hipMemcpyAsync(rho_ptrs.p, hp.data(), n * sizeof(double*), hipMemcpyHostToDevice, stream_));
+  if (ci.type == 0) {
+    coupling_coefs_k<<<1, 64, 0, stream_>>>(ci.coef.d(), rho_ptrs.as<const double*>(), n);
+    AO_KERNEL_CHECK();
+  } else {
+    AAArgs aa;
+    aa.n = n; aa.Rc = (int)ci.cols;
+    for (int j = 0; j < n; ++j) { aa.H[j] = modes_[ci.modes[j]].H.d(); aa.rho[j] = hp[j]; aa.R[j] = modes_[ci.modes[j]].R; }
+    coupling_AA_k<<<1, 256, 0, stream_>>>(ci.AA.d(), aa);
+    AO_KERNEL_CHECK();
+    chol_only(ci.LAA.d(), ci.AA.d(), (int)ci.cols, ctl, stream_);
+  }
+  for (int it = 0; it < opt.MaxInnerIters; ++it) {
+    // ---- primal updates (:635-658 / :913-936)
+    for (int j = 0; j < n; ++j) {
+      ModeInfo& mi = modes_[ci.modes[j]];
+      coupling_image(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_);
+      Coef cf[5] = {coef(1.0), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), -0.5), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), -0.5)};
+      const double* x[5] = {mi.Aeff, mi.TD.d(), mi.muD.d(), mi.Z.d(), mi.mu.d()};
+      ew_lincomb(mi.RHS.d(), mi.rows * mi.R, mi.constrained ? 5 : 3, cf, x, ctl, stream_);
+      row_solve(mi.fac.d(), mi.rows, mi.RHS.d(), mi.rows, mi.L.d(), mi.rows, mi.R, ctl, stream_);
+    }
+    // ---- Delta update
+    {
+      Coef c1[1] = {coef(1.0)};
+      const double* x1[1] = {ci.Delta.d()};
+      ew_lincomb(ci.DeltaOld.d(), nD, 1, c1, x1, ctl, stream_);
+    }
+    if (ci.type == 0) {
+      for (int j = 0; j < n; ++j) {
+        ModeInfo& mi = modes_[ci.modes[j]];
+        if (j == 0) {
+          Coef cf[2] = {coef(ci.coef.d() + j, 1.0), coef(ci.coef.d() + j, 1.0)};
+          const double* x[2] = {mi.fac.d(), mi.muD.d()};
+          ew_lincomb(ci.Delta.d(), nD, 2, cf, x, ctl, stream_);
+        } else {
+          Coef cf[3] = {coef(1.0), coef(ci.coef.d() + j, 1.0), coef(ci.coef.d() + j, 1.0)};
+          const double* x[3] = {ci.Delta.d(), mi.fac.d(), mi.muD.d()};
+          ew_lincomb(ci.Delta.d(), nD, 3, cf, x, ctl, stream_);
+        }
+      }
+    } else {
+      for (int j = 0; j < n; ++j) {
+        ModeInfo& mi = modes_[ci.modes[j]];
+        Coef cf[2] = {coef(1.0), coef(1.0)};
+        const double* x[2] = {mi.fac.d(), mi.muD.d()};
+        ew_lincomb(mi.tmp.d(), mi.rows * mi.R, 2, cf, x, ctl, stream_);
+        // BB += rho_j * (fac+mu) * H_j'   (:955)
+        gemm_small(ci.BB.d(), ci.rows, mi.tmp.d(), mi.rows, mi.H.d(), mi.hr, ci.rows, mi.R, (int)ci.cols, 1,
+                   coef(mi.rho.d(), 1.0), j == 0 ? 0.0 : 1.0, ctl, stream_);
+      }
+      row_solve(ci.Delta.d(), ci.rows, ci.BB.d(), ci.rows, ci.LAA.d(), ci.rows, (int)ci.cols, ctl, stream_);  // BB/AA (:962)
+    }
+    {
+      Coef cf[2] = {coef(1.0), coef(-1.0)};
+      const double* x[2] = {ci.Delta.d(), ci.DeltaOld.d()};
+      ew_lincomb(ci.dD.d(), nD, 2, cf, x, ctl, stream_);
+    }
+    // ---- duals, constraints, residual pieces (:678-692 / :966-980)
+    FinalizeArgs fa;
+    fa.nmodes = n;
+    fa.max_inner = opt.MaxInnerIters;
+    fa.tol_pr_coupl = opt.innerRelPrTol_coupl; fa.tol_pr_constr = opt.innerRelPrTol_constr;
+    fa.tol_du_coupl = opt.innerRelDualTol_coupl; fa.tol_du_constr = opt.innerRelDualTol_constr;
+    for (int j = 0; j < n; ++j) {
+      const int m = ci.modes[j];
+      ModeInfo& mi = modes_[m];
+      double* sl = resid + (int64_t)m * kResidPerMode;
+      const int64_t nm = mi.rows * mi.R;
+      coupling_image(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_);
+      Coef cf[3] = {coef(1.0), coef(1.0), coef(-1.0)};
+      const double* x[3] = {mi.muD.d(), mi.fac.d(), mi.TD.d()};
+      ew_lincomb(mi.muD.d(), nm, 3, cf, x, ctl, stream_);                      // mu_Delta update
+      if (mi.constrained)
+        constraint_update(mi.prox, mi.fac.d(), mi.Z.d(), mi.mu.d(), mi.Zold.d(), mi.V.d(), mi.rows, mi.R,
+                          mi.rho.d(), 1.0, mi.proxws.d(), sl, redws_.d(), ctl, stream_);
+      else
+        sumsq_diff(sl + 1, mi.fac.d(), nullptr, nm, redws_.d(), ctl, stream_);
+      sumsq_diff(sl + 4, mi.fac.d(), mi.TD.d(), nm, redws_.d(), ctl, stream_);
+      sumsq_diff(sl + 5, mi.muD.d(), nullptr, nm, redws_.d(), ctl, stream_);
+      coupling_image(mi.tmp.d(), ci, ci.dD.d(), mi, ctl, stream_);
+      sumsq_diff(sl + 6, mi.tmp.d(), nullptr, nm, redws_.d(), ctl, stream_);
+      fa.slots[j] = sl;
+      fa.constrained[j] = mi.constrained ? 1 : 0;
+      fa.coupled[j] = 1;
+    }
+    admm_finalize_generic(fa, ctl, stream_);
+  }
+  AO_HIP(hipStreamSynchronize(stream_));     // rho_ptrs goes out of scope
+}
+
+// ---------------------------------------------------------------------------
+// objective (CMTF_AOADMM_func_eval, :1213-1363)
+// ---------------------------------------------------------------------------
+void Engine::eval_objective_enqueue(bool first) {
+  double* S = slots_.d();
+  for (int p = 0; p < n_tensors_; ++p) {
+    TensorInfo& t = tensors_[p];
+    if (first) {
+      // cp_func.m:47-55 / pca_func.m:29-39: same formula with the first mode's MTTKRP
+      ModeInfo& m0 = modes_[t.modes[0]];
+      FactorRef facs[8];
+      for (int i = 0; i < t.nmodes; ++i) {
+        const ModeInfo& o = modes_[t.modes[i]];
+        facs[i] = FactorRef{o.fac.d(), o.rows, o.version};
+      }
+      std::vector<int> seq = update_sequence(p);
+      block_mttkrp(t.blk, 0, facs, m0.R, t.weight, m0.A.d(), m0.rows, true, seq.data(), (int)seq.size());
+      SysBuild sb;
+      sb.ngram = 0;
+      for (int i = 1; i < t.nmodes; ++i) sb.grams[sb.ngram++] = modes_[t.modes[i]].gram.d();
+      sb.Cpre = nullptr; sb.w = t.weight; sb.ridge = 0; sb.bsum_half = 0; sb.rho_scale = 1; sb.nrho = 1; sb.R = m0.R;
+      sb.C = m0.C.d(); sb.rho = m0.rho.d(); sb.Bsys = m0.Bsys.d(); sb.L = m0.L.d(); sb.ctl = nullptr;
+      sys_build(sb, stream_);
+      t.last_pos = 0;
+    }
+    ModeInfo& lm = modes_[t.modes[t.last_pos]];
+    double* sp = S + n_modes_ * kSlotsPerMode + 2 * p;
+    dot(sp + 0, lm.A.d(), lm.fac.d(), lm.rows * lm.R, redws_.d(), nullptr, stream_);       // f_2 * w
+    dot(sp + 1, lm.C.d(), lm.gram.d(), (int64_t)lm.R * lm.R, redws_.d(), nullptr, stream_);  // f_3
+  }
+  for (int m = 0; m < n_modes_; ++m) {
+    ModeInfo& mi = modes_[m];
+    double* sm = S + (int64_t)m * kSlotsPerMode;
+    const int64_t nm = mi.rows * mi.R;
+    sumsq_diff(sm + 0, mi.fac.d(), nullptr, nm, redws_.d(), nullptr, stream_);
+    if (mi.constrained) {
+      sumsq_diff(sm + 1, mi.fac.d(), mi.Z.d(), nm, redws_.d(), nullptr, stream_);
+      const int ty = mi.prox.type;
+      if (ty == AOADMM_C_L1_REG || ty == AOADMM_C_L0_REG || ty == AOADMM_C_L2_REG || ty == AOADMM_C_RIDGE ||
+          ty == AOADMM_C_GL_SMOOTH || ty == AOADMM_C_TV)
+        reg_value(sm + 3, ty, mi.prox.p0, mi.fac.d(), mi.rows, mi.R, redws_.d(), stream_);
+    }
+    if (mi.coupling >= 0) {
+      CouplingInfo& ci = couplings_[mi.coupling];
+      coupling_image(mi.TD.d(), ci, ci.Delta.d(), mi, nullptr, stream_);
+      sumsq_diff(sm + 2, mi.fac.d(), mi.TD.d(), nm, redws_.d(), nullptr, stream_);
+    }
+  }
+}
+
+static bool stop_one(double f, double fo, const aoadmm_options& o) {
+  const double rel = fo > 0 ? std::fabs(fo - f) / fo : std::fabs(fo - f);    // evaluate_stopping_conditions.m:8-15
+  return f < o.AbsFuncTol || rel < o.OuterRelTol;
+}
+
+void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
+  AO_REQUIRE(model_done_, "call aoadmm_model_end first");
+  AO_REQUIRE(out != nullptr, "null result");
+  AO_REQUIRE(opt.MaxOuterIters >= 0 && opt.MaxInnerIters >= 1, "bad iteration limits");
+  AO_HIP(hipSetDevice(device_));
+  for (int p = 0; p < n_tensors_; ++p) {
+    AO_REQUIRE(tensors_[p].blk.has_data, "tensor %d has no data (Z.object{%d})", p, p + 1);
+    AO_REQUIRE(tensors_[p].nmodes <= 3, "tensors of order > 3 are not in the device path yet");
+    (void)tensor_normsq(p);
+  }
+  for (int m = 0; m < n_modes_; ++m) {
+    ModeInfo& mi = modes_[m];
+    AO_REQUIRE(mi.has_fac, "G.fac{%d} missing", m + 1);
+    if (mi.constrained) AO_REQUIRE(mi.has_Z && mi.has_mu, "G.constraint_fac{%d} / constraint_dual_fac{%d} missing", m + 1, m + 1);
+    if (mi.coupling >= 0) {
+      AO_REQUIRE(mi.has_muD && mi.muD_rows == mi.rows && mi.muD_cols == mi.R, "G.coupling_dual_fac{%d} missing or mis-sized", m + 1);
+      AO_REQUIRE(couplings_[mi.coupling].has_state, "G.coupling_fac{%d} missing", mi.coupling + 1);
+    }
+    ensure_mode_work(mi);
+    compute_gram(mi);                                                        // :62-81
+  }
+  const int nctl = n_modes_ + n_couplings_;
+  std::vector<AdmmCtl> hctl(nctl);
+  const int nslots = n_modes_ * kSlotsPerMode + 2 * n_tensors_;
+  std::vector<double> hs(nslots);
+
+  auto finish_eval = [&](double f[4]) {
+    AO_HIP(hipMemcpyAsync(hs.data(), slots_.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    AO_HIP(hipMemcpyAsync(hctl.data(), ctls_.p, nctl * sizeof(AdmmCtl), hipMemcpyDeviceToHost, stream_));
+    AO_HIP(hipStreamSynchronize(stream_));
+    for (int i = 0; i < nctl; ++i)
+      if (hctl[i].notpd)
+        throw Error(AOADMM_ERR_NOT_PD, "Cholesky failed: system matrix is not positive definite (chol in cmtf_fun_AOADMM.m:142/273/362)");
+    double ft = 0.0;
+    for (int p = 0; p < n_tensors_; ++p) {
+      const TensorInfo& t = tensors_[p];
+      const double* sp = hs.data() + n_modes_ * kSlotsPerMode + 2 * p;
+      const double f2 = sp[0] / t.weight;                                     // last_mttkrp = A*1/w (:121)
+      ft += t.weight * (t.normsq - 2.0 * f2 + sp[1]);                          // :1235-1241
+    }
+    double fcon = 0.0; int ncon = 0;
+    std::vector<double> cp(n_couplings_, 0.0);
+    for (int m = 0; m < n_modes_; ++m) {
+      const ModeInfo& mi = modes_[m];
+      const double* sm = hs.data() + (int64_t)m * kSlotsPerMode;
+      const double nf = std::sqrt(sm[0]);
+      if (mi.constrained) {
+        const int ty = mi.prox.type;
+        if (ty == AOADMM_C_L1_REG || ty == AOADMM_C_L0_REG || ty == AOADMM_C_L2_REG || ty == AOADMM_C_RIDGE ||
+            ty == AOADMM_C_GL_SMOOTH || ty == AOADMM_C_TV)
+          ft += sm[3];                                                         // reg_func (:1272-1288)
+        const double g = std::sqrt(sm[1]) / nf;                               // :1341
+        fcon += g;
+        if (g != 0.0) ++ncon;
+      }
+      if (has_ridge_) ft += mi.ridge * sm[0];                                  // :1297
+      if (mi.coupling >= 0) cp[mi.coupling] += std::sqrt(sm[2]) / nf;         // :1311,:1319
+    }
+    double fc = 0.0; int nc = 0;
+    for (double v : cp) { fc += v; if (v != 0.0) ++nc; }
+    if (fc > 0) fc /= nc;                                                      // :1327-1329
+    if (fcon > 0) fcon /= ncon;                                                // :1346-1348
+    f[0] = ft; f[1] = fc; f[2] = fcon; f[3] = 0.0;
+  };
+
+  double f[4], fo[4];
+  eval_objective_enqueue(true);                                                // :32
+  finish_eval(f);
+  if (out->func_val_conv) out->func_val_conv[0] = f[0];
+  if (out->func_coupl_conv) out->func_coupl_conv[0] = f[1];
+  if (out->func_constr_conv) out->func_constr_conv[0] = f[2];
+  if (out->func_PAR2_coupl) out->func_PAR2_coupl[0] = f[3];
+  if (out->time_at_it) out->time_at_it[0] = 0.0;
+  const auto t0 = std::chrono::steady_clock::now();
+
+  int iter = 1;
+  bool stop = false;
+  while (iter <= opt.MaxOuterIters && !stop) {                                 // :87
+    for (int cid = -1; cid < n_couplings_; ++cid) {                            // :89 (0 = uncoupled first)
+      std::vector<int> cm;
+      for (int m = 0; m < n_modes_; ++m)
+        if (modes_[m].coupling == cid) cm.push_back(m);
+      if (cm.empty()) continue;
+      std::set<int> ps;
+      for (int m : cm) ps.insert(modes_[m].tensor);
+      for (int p : ps)                                                         // :91
+        for (int m : cm)                                                       // :93
+          if (modes_[m].tensor == p) {
+            if (cid < 0) update_uncoupled_cp_mode(m, opt);
+            else prepare_mode_system(m, 1 + (modes_[m].constrained ? 1 : 0), opt);   // :269-273 / :358-362
+          }
+      if (cid >= 0) {
+        coupled_admm(cid, opt);                                                // :277 / :366
+        for (int m : cm) { compute_gram(modes_[m]); modes_[m].version++; }      // :393-403
+      }
+    }
+    for (int i = 0; i < 4; ++i) fo[i] = f[i];
+    eval_objective_enqueue(false);                                             // :447
+    finish_eval(f);
+    if (out->func_val_conv) out->func_val_conv[iter] = f[0];
+    if (out->func_coupl_conv) out->func_coupl_conv[iter] = f[1];
+    if (out->func_constr_conv) out->func_constr_conv[iter] = f[2];
+    if (out->func_PAR2_coupl) out->func_PAR2_coupl[iter] = f[3];
+    if (out->time_at_it)
+      out->time_at_it[iter] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (out->innerIters) {
+      for (int m = 0; m < n_modes_; ++m) {
+        const ModeInfo& mi = modes_[m];
+        double v;
+        if (mi.coupling >= 0) v = hctl[n_modes_ + mi.coupling].iters;          // :392
+        else if (mi.constrained) v = hctl[m].iters;                            // :146
+        else v = 1;                                                            // :138
+        out->innerIters[(int64_t)(iter - 1) * n_modes_ + m] = v;
+      }
+    }
+    stop = stop_one(f[0], fo[0], opt) && stop_one(f[1], fo[1], opt) && stop_one(f[2], fo[2], opt) &&
+           stop_one(f[3], fo[3], opt);                                         // :456
+    ++iter;
+  }
+  out->f_tensors = f[0]; out->f_couplings = f[1]; out->f_constraints = f[2]; out->f_PAR2_couplings = f[3];
+  out->OuterIterations = iter - 1;
+  out->exit_code = iter > opt.MaxOuterIters ? 0 : 1;                           // make_exit_flag.m:4-5
+  for (int i = 0; i < 4; ++i) out->exit_abs[i] = f[i] < opt.AbsFuncTol ? 1 : 0;
+}
+
+void Engine::resident_mttkrp(int p, int pos, double* out_host, float* ms) {
+  AO_REQUIRE(model_done_, "call aoadmm_model_end first");
+  AO_REQUIRE(p >= 0 && p < n_tensors_, "tensor %d out of range", p);
+  AO_HIP(hipSetDevice(device_));
+  TensorInfo& t = tensors_[p];
+  AO_REQUIRE(pos >= 0 && pos < t.nmodes, "tensor mode %d out of range", pos);
+  FactorRef facs[8];
+  for (int i = 0; i < t.nmodes; ++i) {
+    ModeInfo& o = modes_[t.modes[i]];
+    AO_REQUIRE(o.has_fac, "G.fac{%d} missing", t.modes[i] + 1);
+    facs[i] = FactorRef{o.fac.d(), o.rows, o.version};
+  }
+  ModeInfo& mi = modes_[t.modes[pos]];
+  ensure_mode_work(mi);
+  hipEvent_t e0, e1;
+  AO_HIP(hipEventCreate(&e0)); AO_HIP(hipEventCreate(&e1));
+  AO_HIP(hipEventRecord(e0, stream_));
+  block_mttkrp(t.blk, pos, facs, mi.R, 1.0, mi.A.d(), mi.rows, false, nullptr, 0);
+  AO_HIP(hipEventRecord(e1, stream_));
+  AO_HIP(hipEventSynchronize(e1));
+  float tms = 0.f;
+  AO_HIP(hipEventElapsedTime(&tms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (ms) *ms = tms;
+  if (out_host) {
+    AO_HIP(hipMemcpyAsync(out_host, mi.A.p, (size_t)mi.rows * mi.R * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    AO_HIP(hipStreamSynchronize(stream_));
+  }
+}
+
+}  // namespace aoadmm

@@ -1,0 +1,418 @@
+"""Host-side mirror of the reference's public interface, running on the HIP engine.
+
+    Zhat, Fac, G, out = cmtf_AOADMM(Z, alg_options=options, init=G|'random', init_options=init)
+    G = init_coupled_AOADMM_CMTF(Z, init_options=init[, Delta=...])
+    prox, reg = constraints_to_prox(constrained_modes, constraints, sz)
+
+Same names, argument meaning and error behaviour as `functions/cmtf_AOADMM.m:1-206`,
+`functions/init_coupled_AOADMM_CMTF.m:1-174` and `functions/constraints_to_prox.m:1-94`.
+The structs are Python dicts with the MATLAB field names; `Z['modes']` keeps
+MATLAB's 1-based mode numbers and `lin_coupled_modes` its 1-based coupling ids
+(0 = uncoupled), so the example scripts translate line by line.
+
+What this layer does is exactly what the MEX gateway does for MATLAB
+(`matlab-code_amd/mex/`): validate, turn constraint cells into descriptors,
+marshal arrays column-major through the C ABI, run `aoadmm_solve` (which replaces
+`cmtf_fun_AOADMM`, cmtf_AOADMM.m:193), and pack `Zhat/Fac/out`.  Features the
+device path does not cover raise `UnsupportedOnDevice` so a caller can fall
+back to the original MATLAB implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from .engine import Engine, constraint_descriptor, default_engine
+
+
+def _which_p(Z):
+    nb_modes = len(Z['size'])
+    out = [None] * nb_modes
+    for i in range(nb_modes):
+        for p, ms in enumerate(Z['modes']):
+            if (i + 1) in list(ms):
+                out[i] = p
+    if any(v is None for v in out) or max(max(ms) for ms in Z['modes']) != nb_modes:
+        raise ValueError('Mismatch between size and modes inputs')     # init_coupled_AOADMM_CMTF.m:32-35
+    return out
+
+
+def constraints_to_prox(constrained_modes, constraints, sz, engine=None):
+    """functions/constraints_to_prox.m:1-94 -- returns (prox_operators, reg_func).
+
+    Each prox operator is a callable `(x, rho) -> array` evaluated by the HIP
+    kernels (op-level entry `aoadmm_op_prox`); `reg_func` entries are host
+    closures (they are only used for reporting).
+    """
+    eng = engine or default_engine()
+    n = len(constrained_modes)
+    prox_ops = [None] * n
+    reg = [None] * n
+    for m in range(n):
+        if not constrained_modes[m]:
+            continue
+        c = constraints[m]
+        if c is None or len(c) == 0:
+            raise ValueError('No constraint provided for mode %d.' % (m + 1))
+        constraint_descriptor(c)     # validates / raises UnsupportedOnDevice
+        prox_ops[m] = (lambda x, rho, c=c: eng.prox(c, x, rho))
+        name = c[0]
+        if name == 'l1 regularization':
+            reg[m] = lambda x, eta=c[1]: eta * np.sum(np.abs(x))
+        elif name == 'l0 regularization':
+            reg[m] = lambda x, eta=c[1]: eta * float(np.count_nonzero(x))
+        elif name == 'l2 regularization':
+            reg[m] = lambda x, eta=c[1]: eta * np.sum(np.sqrt(np.sum(x * x, axis=0)))
+        elif name == 'ridge':
+            reg[m] = lambda x, eta=c[1]: eta * np.linalg.norm(x, 'fro') ** 2
+        elif name == 'TV regularization':
+            reg[m] = lambda x, eta=c[1]: eta * np.sum(x[1:, :] - x[:-1, :])     # quirk of :81 kept
+        elif name == 'GL smoothness':
+            reg[m] = lambda x, eta=c[1]: eta * np.sum((x[1:, :] - x[:-1, :]) ** 2)
+    return prox_ops, reg
+
+
+def init_coupled_AOADMM_CMTF(Z, init_options, Delta=None, rng=None, engine=None):
+    """functions/init_coupled_AOADMM_CMTF.m:1-174 (random path, `nvecs = 0`)."""
+    if rng is None:
+        rng = np.random.default_rng()
+    if init_options.get('nvecs', 0):
+        raise capi.UnsupportedOnDevice(capi.ERR_UNSUPPORTED, 'nvecs initialisation (cmtf_nvecs.m) stays on the MATLAB path')
+    sz = Z['size']
+    lambdas = init_options['lambdas_init']
+    distr = init_options['distr']
+    normalize = init_options['normalize']
+    nb_modes = len(sz)
+    _which_p(Z)
+    lin = [int(v) for v in Z['coupling']['lin_coupled_modes']]
+    nb_couplings = max(lin) if lin else 0
+    ctm = Z['coupling'].get('coupl_trafo_matrices', [None] * nb_modes)
+    P = len(Z['modes'])
+    A = {'fac': [None] * nb_modes, 'coupling_fac': [None] * nb_couplings, 'constraint_fac': [None] * nb_modes,
+         'coupling_dual_fac': [None] * nb_modes, 'constraint_dual_fac': [None] * nb_modes,
+         'DeltaB': {}, 'P': {}, 'mu_DeltaB': {}}
+
+    def colnorm(M):
+        return M / np.sqrt(np.sum(M * M, axis=0))[None, :]
+
+    for p in range(P):
+        md = [m - 1 for m in Z['modes'][p]]
+        R = len(lambdas[p])
+        for n in md:
+            if Z['model'][p] == 'PAR2' and md.index(n) == 1:
+                A['DeltaB'][p] = rng.random((R, R))
+                A['fac'][n] = []
+                A['P'][p] = []
+                A['mu_DeltaB'][p] = []
+                for k in range(len(sz[n])):
+                    F = np.asarray(distr[n](sz[n][k], R), dtype=np.float64)
+                    A['P'][p].append(np.eye(sz[n][k], R))
+                    A['mu_DeltaB'][p].append(rng.random((sz[n][k], R)))
+                    A['fac'][n].append(colnorm(F) if normalize else F)
+            else:
+                F = np.asarray(distr[n](sz[n], R), dtype=np.float64)
+                A['fac'][n] = colnorm(F) if normalize else F
+    if any(Z['constrained_modes']):
+        prox_ops, _ = constraints_to_prox(Z['constrained_modes'], Z['constraints'], sz, engine)
+        for p in range(P):
+            md = [m - 1 for m in Z['modes'][p]]
+            for n in md:
+                if not Z['constrained_modes'][n]:
+                    continue
+                if Z['model'][p] == 'PAR2' and md.index(n) == 1:
+                    A['constraint_fac'][n] = []
+                    A['constraint_dual_fac'][n] = []
+                    for k in range(len(sz[n])):
+                        Zk = np.asarray(distr[n](*A['fac'][n][k].shape), dtype=np.float64)
+                        if Z['constraints'][n][0] != 'tPARAFAC2':
+                            Zk = prox_ops[n](Zk, 1.0)
+                        A['constraint_fac'][n].append(Zk)
+                        A['constraint_dual_fac'][n].append(rng.random(A['fac'][n][k].shape))
+                else:
+                    if Z['constraints'][n][0] == 'tPARAFAC2':
+                        raise ValueError('The tPARAFAC2 constraint can only be impsed on the second mode of a PARAFAC2 model')
+                    Zn = np.asarray(distr[n](*A['fac'][n].shape), dtype=np.float64)
+                    A['constraint_fac'][n] = prox_ops[n](Zn, 1.0)
+                    A['constraint_dual_fac'][n] = rng.random(A['fac'][n].shape)
+    for n in range(nb_couplings):
+        cmodes = [i for i, v in enumerate(lin) if v == n + 1]
+        mode1 = cmodes[0]
+        ct = int(Z['coupling']['coupling_type'][n])
+        F1 = A['fac'][mode1]
+        if ct == 0:
+            A['coupling_fac'][n] = rng.random(F1.shape)
+            for m in cmodes:
+                A['coupling_dual_fac'][m] = rng.random(A['coupling_fac'][n].shape)
+        elif ct == 1:
+            A['coupling_fac'][n] = rng.random((ctm[mode1].shape[0], F1.shape[1]))
+            for m in cmodes:
+                A['coupling_dual_fac'][m] = rng.random(A['coupling_fac'][n].shape)
+        elif ct == 2:
+            A['coupling_fac'][n] = rng.random((F1.shape[0], ctm[mode1].shape[1]))
+            for m in cmodes:
+                A['coupling_dual_fac'][m] = rng.random(A['coupling_fac'][n].shape)
+        elif ct == 3:
+            A['coupling_fac'][n] = rng.random((ctm[mode1].shape[1], F1.shape[1]))
+            for m in cmodes:
+                A['coupling_dual_fac'][m] = rng.random(A['fac'][m].shape)
+        elif ct == 4:
+            A['coupling_fac'][n] = rng.random((F1.shape[0], ctm[mode1].shape[0]))
+            for m in cmodes:
+                A['coupling_dual_fac'][m] = rng.random(A['fac'][m].shape)
+        else:
+            A['coupling_fac'][n] = rng.random(np.shape(Delta[n]))
+            for m in cmodes:
+                A['coupling_dual_fac'][m] = rng.random((A['coupling_fac'][n].shape[0], A['fac'][m].shape[1]))
+    return A
+
+
+def _make_options(alg_options):
+    o = capi.Options()
+    for name in ('MaxOuterIters', 'MaxInnerIters', 'AbsFuncTol', 'OuterRelTol', 'innerRelPrTol_coupl',
+                 'innerRelPrTol_constr', 'innerRelDualTol_coupl', 'innerRelDualTol_constr', 'bsum'):
+        if name not in alg_options:
+            raise KeyError("Reference to non-existent field '%s'." % name)   # MATLAB: missing option field errors
+        setattr(o, name, alg_options[name])
+    o.bsum = int(bool(alg_options['bsum']))
+    if o.bsum:
+        o.bsum_weight = float(alg_options['bsum_weight'])
+    o.iter_start_PAR2Bkconstraint = int(alg_options.get('iter_start_PAR2Bkconstraint', 0))   # cmtf_fun_AOADMM.m:7-9
+    if 'increase_factor_rhoBk' in alg_options:
+        o.has_increase_factor_rhoBk = 1
+        o.increase_factor_rhoBk = float(alg_options['increase_factor_rhoBk'])
+    hip = alg_options.get('hip', {})
+    o.use_dimtree = int(hip.get('use_dimtree', 1))
+    return o
+
+
+def build_model(eng, Z, precision='f64'):
+    """Describe the struct Z to the engine and upload Z.object (cmtf_AOADMM.m:23-41,124-156)."""
+    lib = eng.lib
+    nb_modes = len(Z['size'])
+    which_p = _which_p(Z)
+    P = len(Z['object'])
+    lin = [int(v) for v in Z['coupling']['lin_coupled_modes']]
+    nb_couplings = max(lin) if lin else 0
+    if nb_couplings != len(Z['coupling']['coupling_type']):
+        raise ValueError('Mismatch between number of coulings and coupling types')   # check_data_input.m:17-19
+    for p in range(P):
+        if Z['loss_function'][p] != 'Frobenius':
+            raise capi.UnsupportedOnDevice(capi.ERR_UNSUPPORTED,
+                                           "loss '%s' needs the L-BFGS-B path of the MATLAB code" % Z['loss_function'][p])
+    if Z.get('miss') is not None and any(m is not None for m in Z['miss']):
+        raise capi.UnsupportedOnDevice(capi.ERR_UNSUPPORTED, 'Z.miss (EM imputation) stays on the MATLAB path')
+    capi.check(lib.aoadmm_model_begin(eng.h, nb_modes, P, nb_couplings))
+    R_of = {}
+    for p in range(P):
+        md = [m - 1 for m in Z['modes'][p]]
+        for m in md:
+            R_of[m] = None
+    # ranks come from the initial factors when given; here from the caller via Z['_ranks']
+    ranks = Z['_ranks']
+    for m in range(nb_modes):
+        p = which_p[m]
+        md = [q - 1 for q in Z['modes'][p]]
+        if Z['model'][p] == 'PAR2' and md.index(m) == 1:
+            rows = (C.c_int64 * len(Z['size'][m]))(*[int(v) for v in Z['size'][m]])
+            capi.check(lib.aoadmm_model_set_mode_slabs(eng.h, m, len(Z['size'][m]), rows, int(ranks[m])))
+        else:
+            capi.check(lib.aoadmm_model_set_mode(eng.h, m, int(Z['size'][m]), int(ranks[m])))
+    for p in range(P):
+        md = [m - 1 for m in Z['modes'][p]]
+        arr = (C.c_int * len(md))(*md)
+        if Z['model'][p] == 'CP':
+            capi.check(lib.aoadmm_model_add_cp(eng.h, p, len(md), arr, float(Z['weights'][p])))
+        elif Z['model'][p] == 'PAR2':
+            capi.check(lib.aoadmm_model_add_par2(eng.h, p, arr, float(Z['weights'][p])))
+        else:
+            raise ValueError("unknown model '%s'" % Z['model'][p])
+    for m in range(nb_modes):
+        if Z['constrained_modes'][m]:
+            c = Z['constraints'][m]
+            if c is None or len(c) == 0:
+                raise ValueError('No constraint provided for mode %d.' % (m + 1))       # constraints_to_prox.m:10-12
+            cid, params, Lmat = constraint_descriptor(c)
+            capi.check(lib.aoadmm_model_set_constraint(eng.h, m, cid, capi.dptr(params) if params.size else None,
+                                                       params.size, capi.dptr(Lmat) if Lmat is not None else None))
+    ctm = Z['coupling'].get('coupl_trafo_matrices', [None] * nb_modes)
+    ctm2 = Z['coupling'].get('coupl_trafo_matrices2', [None] * nb_modes)
+    keep = []
+    for m in range(nb_modes):
+        H = capi.as_f(ctm[m]) if (lin[m] and ctm[m] is not None) else None
+        H2 = capi.as_f(ctm2[m]) if (lin[m] and ctm2[m] is not None) else None
+        keep += [H, H2]
+        capi.check(lib.aoadmm_model_set_coupling(
+            eng.h, m, lin[m] - 1, capi.dptr(H), H.shape[0] if H is not None else 0, H.shape[1] if H is not None else 0,
+            capi.dptr(H2), H2.shape[0] if H2 is not None else 0, H2.shape[1] if H2 is not None else 0))
+    for n in range(nb_couplings):
+        capi.check(lib.aoadmm_model_set_coupling_type(eng.h, n, int(Z['coupling']['coupling_type'][n])))
+    if Z.get('ridge') is not None:
+        r = np.asarray(Z['ridge'], dtype=np.float64)
+        capi.check(lib.aoadmm_model_set_ridge(eng.h, capi.dptr(r)))
+    capi.check(lib.aoadmm_model_end(eng.h))
+    prec = capi.PREC_F32 if precision == 'f32' else capi.PREC_F64
+    for p in range(P):
+        if Z['model'][p] == 'CP':
+            obj = Z['object'][p]
+            if isinstance(obj, dict) and obj.get('synthetic'):
+                capi.check(lib.aoadmm_tensor_synth(eng.h, p, int(obj['rank']), int(obj['seed']), float(obj['noise']), prec))
+            else:
+                X = capi.as_f(obj)
+                md = [m - 1 for m in Z['modes'][p]]
+                if tuple(X.shape) != tuple(int(Z['size'][m]) for m in md):
+                    raise ValueError('Z.object{%d} has size %s, Z.size says %s' % (p + 1, X.shape, [Z['size'][m] for m in md]))
+                capi.check(lib.aoadmm_tensor_upload(eng.h, p, capi.dptr(X), prec))
+        else:
+            for k, Xk in enumerate(Z['object'][p]):
+                Xk = capi.as_f(Xk)
+                capi.check(lib.aoadmm_par2_slab_upload(eng.h, p, k, capi.dptr(Xk)))
+
+
+def _put(eng, field, index, slab, a):
+    a = capi.as_f(a)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1, order='F')
+    capi.check(eng.lib.aoadmm_state_set(eng.h, field, index, slab, capi.dptr(a), a.shape[0], a.shape[1]))
+
+
+def _get(eng, field, index, slab, shape):
+    out = np.zeros(shape, order='F')
+    capi.check(eng.lib.aoadmm_state_get(eng.h, field, index, slab, capi.dptr(out), shape[0], shape[1]))
+    return out
+
+
+def upload_state(eng, Z, G):
+    """The struct G -> device (init_coupled_AOADMM_CMTF.m:41-45)."""
+    nb_modes = len(Z['size'])
+    for m in range(nb_modes):
+        F = G['fac'][m]
+        if isinstance(F, (list, tuple)):
+            for k, Fk in enumerate(F):
+                _put(eng, capi.F_FAC, m, k, Fk)
+        else:
+            _put(eng, capi.F_FAC, m, 0, F)
+        for field, key in ((capi.F_CONSTRAINT_FAC, 'constraint_fac'), (capi.F_CONSTRAINT_DUAL, 'constraint_dual_fac'),
+                           (capi.F_COUPLING_DUAL, 'coupling_dual_fac')):
+            v = G.get(key, [None] * nb_modes)[m]
+            if v is None or (isinstance(v, (list, tuple)) and len(v) == 0):
+                continue
+            if isinstance(v, (list, tuple)):
+                for k, vk in enumerate(v):
+                    _put(eng, field, m, k, vk)
+            else:
+                _put(eng, field, m, 0, v)
+    for n, D in enumerate(G.get('coupling_fac', [])):
+        if D is not None:
+            _put(eng, capi.F_COUPLING_FAC, n, 0, D)
+    for p, DB in G.get('DeltaB', {}).items():
+        _put(eng, capi.F_DELTAB, p, 0, DB)
+        for k, Pk in enumerate(G['P'][p]):
+            _put(eng, capi.F_P, p, k, Pk)
+        for k, Mk in enumerate(G['mu_DeltaB'][p]):
+            _put(eng, capi.F_MU_DELTAB, p, k, Mk)
+
+
+def download_state(eng, Z, G):
+    """Device -> a struct with the same fields as G (the `Fac` output, cmtf_AOADMM.m:193)."""
+    nb_modes = len(Z['size'])
+    out = {k: (list(v) if isinstance(v, list) else dict(v) if isinstance(v, dict) else v) for k, v in G.items()}
+
+    def pull(field, index, ref):
+        if isinstance(ref, (list, tuple)):
+            return [_get(eng, field, index, k, np.shape(rk)) for k, rk in enumerate(ref)]
+        ref = np.asarray(ref)
+        shp = ref.shape if ref.ndim == 2 else (ref.shape[0], 1)
+        return _get(eng, field, index, 0, shp)
+
+    for m in range(nb_modes):
+        out['fac'][m] = pull(capi.F_FAC, m, G['fac'][m])
+        for field, key in ((capi.F_CONSTRAINT_FAC, 'constraint_fac'), (capi.F_CONSTRAINT_DUAL, 'constraint_dual_fac'),
+                           (capi.F_COUPLING_DUAL, 'coupling_dual_fac')):
+            v = G.get(key, [None] * nb_modes)[m]
+            if v is None or (isinstance(v, (list, tuple)) and len(v) == 0):
+                continue
+            out[key][m] = pull(field, m, v)
+    for n, D in enumerate(G.get('coupling_fac', [])):
+        if D is not None:
+            out['coupling_fac'][n] = pull(capi.F_COUPLING_FAC, n, D)
+    for p, DB in G.get('DeltaB', {}).items():
+        out['DeltaB'][p] = pull(capi.F_DELTAB, p, DB)
+        out['P'][p] = pull(capi.F_P, p, G['P'][p])
+        out['mu_DeltaB'][p] = pull(capi.F_MU_DELTAB, p, G['mu_DeltaB'][p])
+    return out
+
+
+def run_solver(eng, alg_options, nb_modes):
+    """`[Fac,out] = cmtf_fun_AOADMM(...)` (cmtf_AOADMM.m:193) -> the `out` struct (cmtf_fun_AOADMM.m:480-494)."""
+    o = _make_options(alg_options)
+    n = int(o.MaxOuterIters) + 1
+    bufs = {k: np.zeros(n) for k in ('func_val_conv', 'func_coupl_conv', 'func_constr_conv', 'func_PAR2_coupl', 'time_at_it')}
+    inner = np.zeros((nb_modes, max(int(o.MaxOuterIters), 1)), order='F')
+    res = capi.Result()
+    for k, b in bufs.items():
+        setattr(res, k, capi.dptr(b))
+    res.innerIters = capi.dptr(inner)
+    capi.check(eng.lib.aoadmm_solve(eng.h, C.byref(o), C.byref(res)))
+    it = int(res.OuterIterations)
+    out = {
+        'f_tensors': res.f_tensors, 'f_couplings': res.f_couplings, 'f_constraints': res.f_constraints,
+        'f_PAR2_couplings': res.f_PAR2_couplings, 'f_rel_missing': float('nan'),
+        'OuterIterations': it,
+        'innerIters': inner[:, :max(it, 1)].copy(),
+    }
+    for k, b in bufs.items():
+        out[k] = b[:it + 1].copy()
+    names = ['f_tensors', 'f_couplings', 'f_constraints', 'f_PAR2_couplings']
+    if res.exit_code == 0:
+        out['exit_flag'] = 'maxIterations'                                   # make_exit_flag.m:4-5
+    else:
+        out['exit_flag'] = {nm: ('AbsFuncTol' if res.exit_abs[i] else 'RelFuncTol') for i, nm in enumerate(names)}
+    return out
+
+
+def cmtf_AOADMM(Z, alg_options=None, init='random', init_options=None, rng=None, engine=None, precision='f64'):
+    """functions/cmtf_AOADMM.m:1-206.  Returns (Zhat, Fac, G, out)."""
+    if alg_options is None:
+        raise ValueError('alg_options are missing as input in cmtf_AOADMM.')
+    eng = engine or default_engine()
+    Z = dict(Z)
+    which_p = _which_p(Z)
+    for m, c in enumerate(Z['constraints']):                                          # cmtf_AOADMM.m:33-41
+        if Z['constrained_modes'][m] and c is not None and c[0] == 'tPARAFAC2':
+            p = which_p[m]
+            if Z['model'][p] != 'PAR2' or [q - 1 for q in Z['modes'][p]].index(m) != 1:
+                raise ValueError('The tPARAFAC2 constraint can only be impsed on the second mode of a PARAFAC2 model')
+    if isinstance(init, dict):                                                        # :44-53
+        G = init
+    elif isinstance(init, str) and init.lower() == 'random':
+        if init_options is None:
+            raise ValueError('init_options are missing as input in cmtf_AOADMM.')
+        G = init_coupled_AOADMM_CMTF(Z, init_options=init_options, rng=rng, engine=eng)
+    else:
+        raise ValueError('Initialization type not supported')
+    nb_modes = len(Z['size'])
+    ranks = []
+    for m in range(nb_modes):
+        F = G['fac'][m]
+        ranks.append(int((F[0] if isinstance(F, (list, tuple)) else F).shape[1]))
+    for p in range(len(Z['object'])):                                                 # :55-65
+        if Z['model'][p] == 'PAR2':
+            md = [q - 1 for q in Z['modes'][p]]
+            for k, jk in enumerate(Z['size'][md[1]]):
+                if jk < ranks[md[0]]:
+                    raise ValueError('Number of components for PARAFAC2 is larger than size of slice %d of data tensor %d.' % (k + 1, p + 1))
+    Z['_ranks'] = ranks
+    build_model(eng, Z, precision)
+    upload_state(eng, Z, G)
+    out = run_solver(eng, alg_options, nb_modes)
+    Fac = download_state(eng, Z, G)
+    Zhat = []
+    for p in range(len(Z['object'])):                                                 # :197-206
+        md = [q - 1 for q in Z['modes'][p]]
+        if Z['model'][p] == 'CP':
+            Zhat.append([Fac['fac'][m] for m in md])
+        else:
+            Zhat.append({'A': Fac['fac'][md[0]], 'Bk': Fac['fac'][md[1]], 'C': Fac['fac'][md[2]]})
+    return Zhat, Fac, G, out

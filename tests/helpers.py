@@ -1,0 +1,90 @@
+"""Shared test helpers: synthetic models shaped like the reference's example scripts."""
+import numpy as np
+
+from oracle.tensor_ops import full_ktensor
+
+
+def rel_fro(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def options(**kw):
+    """Option struct of example_script1_CP_PAR2_nonneg.m:110-123; tolerances 0 = fixed work."""
+    o = dict(Display='no', DisplayIters=10, MaxOuterIters=10, MaxInnerIters=5, AbsFuncTol=0.0, OuterRelTol=0.0,
+             innerRelPrTol_coupl=0.0, innerRelPrTol_constr=0.0, innerRelDualTol_coupl=0.0,
+             innerRelDualTol_constr=0.0, bsum=0, eps_log=1e-10)
+    o.update(kw)
+    return o
+
+
+def cp_data(dims, R, rng, noise=0.05, nonneg=True):
+    """X = [[A1..AN]] + noise, normalised to ||X|| = 1 (create_coupled_data.m:158-162, example_script1:91-92)."""
+    A = [rng.random((n, R)) if nonneg else rng.standard_normal((n, R)) for n in dims]
+    X = full_ktensor(A)
+    N = rng.standard_normal(X.shape)
+    X = X + noise * np.linalg.norm(X) / np.linalg.norm(N) * N
+    return X / np.linalg.norm(X), A
+
+
+def cp_model(dims, R, rng, constraints, noise=0.05, weight=1.0):
+    """Single uncoupled CP block with one constraint cell per mode (None = unconstrained)."""
+    X, A = cp_data(dims, R, rng, noise)
+    n = len(dims)
+    Z = dict(loss_function=['Frobenius'], model=['CP'], modes=[list(range(1, n + 1))], size=list(dims),
+             coupling=dict(lin_coupled_modes=[0] * n, coupling_type=[], coupl_trafo_matrices=[None] * n),
+             constrained_modes=[0 if c is None else 1 for c in constraints], constraints=list(constraints),
+             weights=[weight], object=[X])
+    io = dict(lambdas_init=[[1] * R], nvecs=0, distr=[(lambda a, b: rng.random((a, b)))] * n, normalize=1)
+    return Z, io, A
+
+
+def script3_model(rng, noise=0.05):
+    """example_script3_matrix_CP_partialcoupling_nonneg.m:23-68: CP 50x30x40 R=4 + matrix 50x70 R=3,
+    modes 1 and 4 coupled with type 4 (C = Delta*H), H1 = eye(4), H4 = [eye(3); 0 0 0]."""
+    D = rng.random((50, 4))
+    A = [D, rng.standard_normal((30, 4)), rng.standard_normal((40, 4))]
+    M = [D[:, :3], rng.random((70, 3))]
+    X1 = full_ktensor(A)
+    X2 = M[0] @ M[1].T
+    for X in (X1, X2):
+        N = rng.standard_normal(X.shape)
+        X += noise * np.linalg.norm(X) / np.linalg.norm(N) * N
+    X1 /= np.linalg.norm(X1)
+    X2 /= np.linalg.norm(X2)
+    H = [None] * 5
+    H[0] = np.eye(4)
+    H[3] = np.vstack([np.eye(3), np.zeros((1, 3))])
+    Z = dict(loss_function=['Frobenius'] * 2, model=['CP', 'CP'], modes=[[1, 2, 3], [4, 5]], size=[50, 30, 40, 50, 70],
+             coupling=dict(lin_coupled_modes=[1, 0, 0, 1, 0], coupling_type=[4], coupl_trafo_matrices=H),
+             constrained_modes=[1, 0, 0, 1, 1],
+             constraints=[('non-negativity',), None, None, ('non-negativity',), ('non-negative l2-sphere', 1)],
+             weights=[0.5, 0.5], object=[X1, X2])
+    distr = [lambda a, b: rng.random((a, b)), lambda a, b: rng.standard_normal((a, b)),
+             lambda a, b: rng.standard_normal((a, b)), lambda a, b: rng.random((a, b)), lambda a, b: rng.random((a, b))]
+    io = dict(lambdas_init=[[1, 1, 1, 1], [1, 1, 1]], nvecs=0, distr=distr, normalize=1)
+    return Z, io
+
+
+def cp_cp_exact_model(rng, noise=0.05):
+    """Two CP tensors sharing their first factor exactly (coupling type 0), non-negative first modes."""
+    R = 3
+    D = rng.random((24, R))
+    A = [D, rng.standard_normal((18, R)), rng.random((20, R))]
+    B = [D, rng.random((16, R)), rng.standard_normal((14, R))]
+    X1 = full_ktensor(A)
+    X2 = full_ktensor(B)
+    for X in (X1, X2):
+        N = rng.standard_normal(X.shape)
+        X += noise * np.linalg.norm(X) / np.linalg.norm(N) * N
+    X1 /= np.linalg.norm(X1)
+    X2 /= np.linalg.norm(X2)
+    Z = dict(loss_function=['Frobenius'] * 2, model=['CP', 'CP'], modes=[[1, 2, 3], [4, 5, 6]],
+             size=[24, 18, 20, 24, 16, 14],
+             coupling=dict(lin_coupled_modes=[1, 0, 0, 1, 0, 0], coupling_type=[0], coupl_trafo_matrices=[None] * 6),
+             constrained_modes=[1, 0, 1, 1, 1, 0],
+             constraints=[('non-negativity',), None, ('non-negativity',), ('non-negativity',), ('box', 0.0, 2.0), None],
+             weights=[0.5, 0.5], object=[X1, X2])
+    distr = [lambda a, b: rng.random((a, b))] * 6
+    io = dict(lambdas_init=[[1] * R, [1] * R], nvecs=0, distr=distr, normalize=1)
+    return Z, io

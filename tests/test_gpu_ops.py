@@ -1,0 +1,104 @@
+"""GPU parity of the op-level C ABI entries against the CPU oracle (tolerances stated per test)."""
+import numpy as np
+import pytest
+
+from oracle import prox as OP
+from oracle import aoadmm as OA
+from oracle.tensor_ops import mttkrp as o_mttkrp
+from helpers import rel_fro
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('dims,R', [((40, 50, 60), 3), ((20, 30, 40), 3), ((50, 30, 40), 4), ((33, 17, 29), 5),
+                                    ((130, 7, 9), 10), ((7, 5, 300), 20), ((64, 64, 64), 20), ((3, 2, 2), 1),
+                                    ((50, 70), 3), ((71, 33), 4), ((257, 129), 17), ((5, 6, 7, 8), 3) ])
+@pytest.mark.parametrize('prec,tol', [('f64', 1e-12), ('f32', 2e-6)])
+def test_mttkrp_matches_oracle(eng, dims, R, prec, tol):
+    """mttkrp(X,U,n) (cmtf_fun_AOADMM.m:97).  fp64 path: 1e-12 relative Frobenius (summation order only);
+    fp32 storage + f32 MFMA: 2e-6 (input rounding 6e-8 * sqrt(reduction length))."""
+    if len(dims) > 3:
+        pytest.skip('order > 3 not in the device path yet')
+    rng = np.random.default_rng(sum(dims) + R)
+    X = rng.standard_normal(dims)
+    U = [rng.standard_normal((n, R)) for n in dims]
+    for n in range(len(dims)):
+        ref = o_mttkrp(X, U, n)
+        got = eng.mttkrp(X, U, n, precision=prec)
+        assert got.shape == ref.shape
+        assert rel_fro(got, ref) < tol, (n, rel_fro(got, ref))
+
+
+def test_mttkrp_asymmetric_layout(eng):
+    """Exact-integer data with an asymmetric factor catches swapped MFMA fragment maps."""
+    I, J, K, R = 131, 6, 5, 7
+    X = np.arange(I * J * K, dtype=np.float64).reshape((I, J, K), order='F') % 17 - 8
+    U = [np.arange(n * R, dtype=np.float64).reshape((n, R), order='F') % 5 - 2 for n in (I, J, K)]
+    for prec in ('f64', 'f32'):
+        for n in range(3):
+            assert np.array_equal(eng.mttkrp(X, U, n, precision=prec), o_mttkrp(X, U, n))
+
+
+def test_gram_and_chol(eng, pkg):
+    rng = np.random.default_rng(3)
+    F = rng.standard_normal((1000, 20))
+    G = eng.gram(F)
+    assert rel_fro(G, F.T @ F) < 1e-13
+    B = F.T @ F + 3.0 * np.eye(20)
+    L = eng.chol(B)
+    assert rel_fro(L, np.linalg.cholesky(B)) < 1e-13
+    with pytest.raises(pkg.NotPositiveDefinite):
+        eng.chol(-np.eye(4))
+
+
+CASES = [
+    ('non-negativity',), ('box', -0.3, 0.4), ('simplex column-wise', 1.0), ('simplex row-wise', 2.0),
+    ('non-decreasing',), ('non-increasing',), ('unimodality', True), ('unimodality', False), ('l1-ball', 3.0),
+    ('l2-ball', 1.0), ('non-negative l2-ball', 1.0), ('non-negative l2-sphere', 1.0), ('orthonormal',),
+    ('l1 regularization', 0.2), ('l0 regularization', 0.2), ('l2 regularization', 0.5), ('ridge', 0.3),
+    ('GL smoothness', 0.7), ('TV regularization', 0.4),
+]
+
+
+@pytest.mark.parametrize('c', CASES, ids=[c[0] + str(c[1:]) for c in CASES])
+@pytest.mark.parametrize('shape', [(60, 3), (257, 20), (1, 4), (2000, 20)])
+def test_prox_matches_oracle(eng, c, shape):
+    """Every device prox equals the oracle's operator to 1e-10 (they are exact algorithms;
+    differences are summation order only)."""
+    rng = np.random.default_rng(hash(c[0]) % 1000 + shape[0])
+    X = rng.standard_normal(shape)
+    if c[0] == 'orthonormal' and shape[0] < shape[1]:
+        pytest.skip('needs rows >= cols')
+    rho = 1.7
+    ops, _ = OP.constraints_to_prox([1], [c], [shape[0]])
+    ref = ops[0](X, rho)
+    got = eng.prox(c, X, rho)
+    assert rel_fro(got, ref) < 1e-10 or np.max(np.abs(got - ref)) < 1e-12, rel_fro(got, ref)
+
+
+def test_sphere_zero_column(eng):
+    X = -np.abs(np.random.default_rng(0).standard_normal((9, 3)))
+    assert np.array_equal(eng.prox(('non-negative l2-sphere', 1), X, 1.0), OP.prox_normalized_nonneg(X))
+
+
+@pytest.mark.parametrize('c', [('non-negativity',), ('TV regularization', 0.01), ('l2-ball', 1.0), ('simplex row-wise', 1.0),
+                               ('unimodality', True)])
+def test_admm_constrained_only(eng, c):
+    """ADMM_constrained_only (cmtf_fun_AOADMM.m:591-623): 5 fixed inner iterations, 1e-11."""
+    rng = np.random.default_rng(5)
+    I, R = 300, 6
+    F = rng.random((400, R))
+    Bsys = F.T @ F
+    rho = float(np.trace(Bsys) / R)
+    A = rng.standard_normal((I, R))
+    fac, Zc, mu = rng.random((I, R)), rng.random((I, R)), rng.random((I, R))
+    ops, _ = OP.constraints_to_prox([1], [c], [I])
+    L = np.linalg.cholesky(Bsys + rho / 2 * np.eye(R))
+    f, z, m = fac.copy(), Zc.copy(), mu.copy()
+    for _ in range(5):
+        f = OA._solve_llt_right(A + rho / 2 * (z - m), L)
+        z = ops[0](f + m, rho)
+        m = m + f - z
+    gf, gz, gm, its = eng.admm_constrained(A, Bsys, rho, c, fac, Zc, mu, 5, 0.0, 0.0)
+    assert its == 5
+    assert rel_fro(gf, f) < 1e-11 and rel_fro(gz, z) < 1e-11 and rel_fro(gm, m) < 1e-11
