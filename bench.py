@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: AO-ADMM outer iterations / second and mode-1 MTTKRP GFLOP/s.
+
+Workload (BASELINE.json configs[4], the config the metric is quoted on; it fits one
+GPU): one 3-way CP block 2000 x 2000 x 2000, rank 20, mode 1 `{'TV regularization',
+0.001}`, modes 2-3 `{'non-negativity'}`, tensor stored fp32 and contracted with
+v_mfma_f32_32x32x2_f32, everything else fp64, MaxInnerIters = 5, all tolerances 0
+(fixed work).  Data: synthetic, generated in HBM; init: seeded rand,
+column-normalised (init_coupled_AOADMM_CMTF.m:88-93,119-124).
+
+One "step" = one outer AO-ADMM iteration (cmtf_fun_AOADMM.m:87-476) through the
+solver-level C ABI entry `aoadmm_solve`.  N > 1 (launched by torchrun, one rank per
+GPU): the tensor's first mode is row-sharded, factor matrices are replicated and
+only MTTKRP outputs are all-reduced over RCCL (strong scaling: total work fixed).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak (spec); ~6.3 TB/s measured achievable
+F32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: f32-input MFMA peak
+
+
+def build_Z(I, J, K, R, seed, noise):
+    return dict(
+        loss_function=['Frobenius'], model=['CP'], modes=[[1, 2, 3]], size=[I, J, K],
+        coupling=dict(lin_coupled_modes=[0, 0, 0], coupling_type=[], coupl_trafo_matrices=[None] * 3),
+        constrained_modes=[1, 1, 1],
+        constraints=[('TV regularization', 0.001), ('non-negativity',), ('non-negativity',)],
+        weights=[1.0], object=[dict(synthetic=True, rank=R, seed=seed, noise=noise)])
+
+
+def cpu_baseline(J, K, R, rows, full_rows):
+    """Oracle (CPU restatement, NOT MATLAB) timed on a bounded sample: one outer iteration on a
+    `rows` x J x K mode-1 slab; the MTTKRP part scales linearly with the slab height."""
+    from oracle import aoadmm as OA
+    from oracle.tensor_ops import full_ktensor
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    A = [rng.random((n, R)) for n in (rows, J, K)]
+    X = full_ktensor(A)
+    X += 0.05 * np.linalg.norm(X) / np.sqrt(X.size) * rng.standard_normal(X.shape)
+    X /= np.linalg.norm(X)
+    Z = dict(loss_function=['Frobenius'], model=['CP'], modes=[[1, 2, 3]], size=[rows, J, K],
+             coupling=dict(lin_coupled_modes=[0, 0, 0], coupling_type=[], coupl_trafo_matrices=[None] * 3),
+             constrained_modes=[1, 1, 1],
+             constraints=[('TV regularization', 0.001), ('non-negativity',), ('non-negativity',)],
+             weights=[1.0], object=[X])
+    io = dict(lambdas_init=[[1] * R], nvecs=0, distr=[lambda a, b: rng.random((a, b))] * 3, normalize=1)
+    opt = dict(Display='no', DisplayIters=1, MaxOuterIters=1, MaxInnerIters=5, AbsFuncTol=0.0, OuterRelTol=0.0,
+               innerRelPrTol_coupl=0.0, innerRelPrTol_constr=0.0, innerRelDualTol_coupl=0.0,
+               innerRelDualTol_constr=0.0, bsum=0)
+    G = OA.init_coupled_AOADMM_CMTF(Z, io, rng=rng)
+    t0 = time.perf_counter()
+    OA.cmtf_AOADMM(Z, alg_options=opt, init=G)
+    dt = time.perf_counter() - t0
+    scale = full_rows / rows
+    return {
+        'value': 1.0 / (dt * scale), 'unit': 'iters/s', 'cores': int(threads), 'kind': 'port',
+        'sample': 'oracle (numpy/OpenBLAS CPU restatement, not MATLAB): 1 outer iteration (+ initial objective) on a '
+                  '%dx%dx%d fp64 mode-1 slab took %.2f s; scaled x%.2f to %d rows' % (rows, J, K, dt, scale, full_rows),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--size', type=int, default=2000)
+    ap.add_argument('--rank', type=int, default=20)
+    ap.add_argument('--prec', default='f32', choices=['f32', 'f64'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-rows', type=int, default=64)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, args.gpus))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)   # control plane only
+    torch.cuda.set_device(local_rank)
+
+    pkg = importlib.import_module('matlab-code_amd')
+    capi = importlib.import_module('matlab-code_amd._capi')
+    eng = pkg.Engine(local_rank)
+    if world > 1:
+        ids = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        eng.comm_init_rank(ids[0], rank, world)       # data plane: RCCL inside the library
+
+    I = J = K = args.size
+    R = args.rank
+    Z = build_Z(I, J, K, R, seed=0, noise=0.05)
+    Z['_ranks'] = [R, R, R]
+    rng = np.random.default_rng(1)                     # identical on every rank: replicated factors
+    io = dict(lambdas_init=[[1] * R], nvecs=0, distr=[lambda a, b: rng.random((a, b))] * 3, normalize=1)
+    t_gen = time.perf_counter()
+    pkg.build_model(eng, Z, args.prec)                 # generates the tensor in HBM
+    G = pkg.init_coupled_AOADMM_CMTF(Z, io, rng=rng, engine=eng)
+    pkg.upload_state(eng, Z, G)
+    eng.synchronize()
+    t_gen = time.perf_counter() - t_gen
+
+    def opts(n):
+        return dict(MaxOuterIters=n, MaxInnerIters=5, AbsFuncTol=0.0, OuterRelTol=0.0, innerRelPrTol_coupl=0.0,
+                    innerRelPrTol_constr=0.0, innerRelDualTol_coupl=0.0, innerRelDualTol_constr=0.0, bsum=0)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        pkg.run_solver(eng, opts(args.warmup), 3)
+    ms = C.c_double(); nl = C.c_int64(); by = C.c_double(); fl = C.c_double()
+    capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 1, C.byref(ms), C.byref(nl), C.byref(by), C.byref(fl)))
+    barrier()
+    t0 = time.perf_counter()
+    out = pkg.run_solver(eng, opts(args.steps), 3)
+    barrier()
+    dt = time.perf_counter() - t0
+    capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 1, C.byref(ms), C.byref(nl), C.byref(by), C.byref(fl)))
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # bare mode-1 MTTKRP on the resident tensor (contraction + reduction), a few repetitions
+    el = C.c_float()
+    reps = []
+    for _ in range(3):
+        capi.check(eng.lib.aoadmm_resident_mttkrp(eng.h, 0, 0, None, C.byref(el)))
+        reps.append(el.value)
+    mttkrp_ms = float(np.median(reps))
+    if dist is not None:
+        tt = torch.tensor([mttkrp_ms], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        mttkrp_ms = float(tt.item())
+    capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 1, None, None, None, None))
+
+    if rank == 0:
+        sx = 4.0 if args.prec == 'f32' else 8.0
+        launches = max(int(nl.value), 1)
+        avg_ms = ms.value / launches
+        bytes_per_launch = by.value / launches
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        flops_mttkrp = 2.0 * I * J * K * R
+        line = {
+            'metric': 'AO-ADMM outer iters/sec (+ mode-1 MTTKRP GFLOP/s), %d^3 rank-%d CP' % (args.size, R),
+            'value': args.steps / dt, 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': args.prec, 'data': 'synthetic',
+            'config': {'workload': 'cfg5: %dx%dx%d R=%d CP, mode1 TV(0.001), modes2-3 nonneg, %s tensor + fp64 solve, '
+                                   'MaxInnerIters=5, tol=0' % (I, J, K, R, args.prec),
+                       'sharding': 'mode-1 rows over %d GPU(s), factors replicated' % world,
+                       'tensor_passes_per_iter': round(launches / args.steps, 2)},
+            'mttkrp_mode1_gflops': flops_mttkrp / (mttkrp_ms * 1e-3) / 1e9,
+            'mttkrp_mode1_ms': mttkrp_ms,
+            'mttkrp_mfma_frac_f32_peak': flops_mttkrp / (mttkrp_ms * 1e-3) / 1e12 / (F32_MFMA_PEAK_TF * world),
+            'f_tensors_last': out['f_tensors'],
+            'datagen_s': t_gen,
+            'roofline': {'bound': 'hbm', 'kernel': 'contract_%s (tensor x factor partial contraction)' % args.prec,
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'avg_launch_ms': avg_ms, 'launches': launches,
+                         'algorithmic_bytes_per_launch': bytes_per_launch,
+                         'note': 'per rank; bytes = local tensor block (s_X) + T written (8*R per unfolding row)'},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                line['cpu_baseline'] = cpu_baseline(J, K, R, min(args.cpu_rows, I), I)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                line['cpu_baseline'] = {'value': None, 'unit': 'iters/s', 'cores': 0, 'kind': 'port',
+                                        'sample': 'failed: %r' % (e,)}
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -42,7 +42,8 @@ ContractPlan make_plan(int64_t nbatch, int64_t batch_stride, int64_t M, int64_t 
 
 // F: device fp64, column-major (C x R) with leading dimension ldF.
 void launch_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
-                     void* frag_ws, double* T, hipStream_t s);
+                     void* frag_ws, double* T, hipStream_t s, hipEvent_t ev0 = nullptr,
+                     hipEvent_t ev1 = nullptr);   // events bracket the contraction kernel only
 
 // out(b,r) = scale * sum_a sum_chunk T[chunk][a + Apad*b][r] * Fa(a,r)      (a < A)
 void launch_reduce_inner(const double* T, int nchunk, int64_t trows, int64_t A, int64_t Apad,

@@ -292,7 +292,7 @@ ContractPlan make_plan(int64_t nbatch, int64_t batch_stride, int64_t M, int64_t 
 }
 
 void launch_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
-                     void* frag_ws, double* T, hipStream_t s) {
+                     void* frag_ws, double* T, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   AO_REQUIRE(pl.R >= 1 && pl.R <= kMaxRank, "rank %d outside [1,%d]", pl.R, kMaxRank);
   const int64_t Cg = cdiv(pl.C, kGroup);
   const int NT = nt_of(pl.R, prec);
@@ -312,6 +312,7 @@ void launch_contract(const void* X, int prec, const ContractPlan& pl, const doub
     int64_t total = (int64_t)NT * Cg * 256;
     pack_frag_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (float*)frag_ws);
     AO_KERNEL_CHECK();
+    if (ev0) AO_HIP(hipEventRecord(ev0, s));
     if (NT == 1) contract_f32<1><<<grid, 256, 0, s>>>(a);
     else if (NT == 2) contract_f32<2><<<grid, 256, 0, s>>>(a);
     else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
@@ -320,12 +321,14 @@ void launch_contract(const void* X, int prec, const ContractPlan& pl, const doub
     int64_t total = (int64_t)NT * Cg * 128;
     pack_frag_f64<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (double*)frag_ws);
     AO_KERNEL_CHECK();
+    if (ev0) AO_HIP(hipEventRecord(ev0, s));
     if (NT == 1) contract_f64<1><<<grid, 256, 0, s>>>(a);
     else if (NT == 2) contract_f64<2><<<grid, 256, 0, s>>>(a);
     else if (NT == 3) contract_f64<3><<<grid, 256, 0, s>>>(a);
     else if (NT == 4) contract_f64<4><<<grid, 256, 0, s>>>(a);
     else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
   }
+  if (ev1) AO_HIP(hipEventRecord(ev1, s));
   AO_KERNEL_CHECK();
 }
 

@@ -437,13 +437,9 @@ void Engine::timed_contract(const void* X, int prec, const ContractPlan& pl, con
   if (profile_ && kstats_.pending.size() < 100000) {
     AO_HIP(hipEventCreate(&e0));
     AO_HIP(hipEventCreate(&e1));
-    AO_HIP(hipEventRecord(e0, stream_));
   }
-  launch_contract(X, prec, pl, F, ldF, frag, T, stream_);
-  if (e0) {
-    AO_HIP(hipEventRecord(e1, stream_));
-    kstats_.pending.emplace_back(e0, e1);
-  }
+  launch_contract(X, prec, pl, F, ldF, frag, T, stream_, e0, e1);
+  if (e0) kstats_.pending.emplace_back(e0, e1);
   kstats_.launches++;
   kstats_.bytes += pl.algorithmic_bytes(prec);
   kstats_.flops += pl.flops();
