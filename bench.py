@@ -108,9 +108,7 @@ def main():
     capi = importlib.import_module('matlab-code_amd._capi')
     eng = pkg.Engine(local_rank)
     if world > 1:
-        ids = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        eng.comm_init_rank(ids[0], rank, world)       # data plane: RCCL inside the library
+        pkg.init_engine_comm(eng, dist)               # data plane: RCCL inside the library
 
     I = J = K = args.size
     R = args.rank

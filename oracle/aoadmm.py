@@ -87,7 +87,8 @@ def _mrdivide(A, B):
 
 
 def _fro(x):
-    return float(np.linalg.norm(x, 'fro')) if np.ndim(x) == 2 else float(np.linalg.norm(x))
+    # numpy scalar on purpose: x/0 gives inf/nan like MATLAB instead of raising
+    return np.float64(np.linalg.norm(x, 'fro')) if np.ndim(x) == 2 else np.float64(np.linalg.norm(x))
 
 
 # --------------------------------------------------------------------------

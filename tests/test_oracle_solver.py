@@ -1,0 +1,95 @@
+"""CPU: the oracle's solver restatement -- definition checks and the known answers the reference's
+example scripts imply (noise-free data => Fit -> 100 %)."""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import aoadmm as OA
+from oracle.tensor_ops import full_ktensor, khatrirao, mttkrp, mttkrp_bruteforce
+from helpers import cp_cp_exact_model, cp_model, options, script3_model
+
+
+@pytest.mark.parametrize('dims', [(4, 5, 6), (3, 7), (2, 3, 4, 5)])
+def test_mttkrp_equals_bruteforce(dims):
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal(dims)
+    U = [rng.standard_normal((n, 3)) for n in dims]
+    for n in range(len(dims)):
+        assert np.allclose(mttkrp(X, U, n), mttkrp_bruteforce(X, U, n), atol=1e-12)
+
+
+def test_khatrirao_ordering_matches_matlab_unfolding():
+    rng = np.random.default_rng(2)
+    A, B = rng.standard_normal((3, 2)), rng.standard_normal((4, 2))
+    KR = khatrirao([A, B])              # row i + 3*j
+    assert np.allclose(KR[1 + 3 * 2], A[1] * B[2])
+    X = full_ktensor([A, B, rng.standard_normal((5, 2))])
+    assert X.shape == (3, 4, 5)
+
+
+def test_noise_free_cp_reaches_full_fit():
+    """example_script1/13/14 property: noise = 0 => Fit ~ 100 % (known answer)."""
+    rng = np.random.default_rng(0)
+    Z, io, _ = cp_model((20, 30, 40), 3, rng, [('non-negativity',)] * 3, noise=0.0)
+    opt = options(MaxOuterIters=2000, AbsFuncTol=1e-14, OuterRelTol=1e-8, innerRelPrTol_constr=1e-5,
+                  innerRelDualTol_constr=1e-5)
+    Zhat, Fac, G, out = OA.cmtf_AOADMM(Z, alg_options=opt, init='random', init_options=io, rng=rng)
+    X = Z['object'][0]
+    fit = 100 * (1 - np.linalg.norm(X - full_ktensor(Zhat[0])) ** 2 / np.linalg.norm(X) ** 2)
+    assert fit > 99.999
+    assert out['OuterIterations'] < 2000 and isinstance(out['exit_flag'], dict)
+    assert out['func_val_conv'].size == out['OuterIterations'] + 1
+    assert out['innerIters'].shape == (3, out['OuterIterations'])
+
+
+def test_objective_fast_path_equals_direct_evaluation():
+    """f_tensors via last_mttkrp/last_had (cmtf_fun_AOADMM.m:1235-1241) == w*||X - model||^2 directly."""
+    rng = np.random.default_rng(3)
+    Z, io, _ = cp_model((9, 8, 7), 2, rng, [('non-negativity',), None, ('box', 0.0, 1.0)], weight=0.7)
+    G = OA.init_coupled_AOADMM_CMTF(Z, io, rng=rng)
+    _, Fac, _, out = OA.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=4), init=G)
+    direct = 0.7 * np.linalg.norm(Z['object'][0] - full_ktensor(Fac['fac'])) ** 2
+    assert np.isclose(out['f_tensors'], direct, rtol=1e-9)
+
+
+def test_update_order_follows_coupling_ids():
+    """Script-3 layout: uncoupled modes 2,3,5 are updated before the coupled modes 1,4
+    (cmtf_fun_AOADMM.m:10,89): after one iteration coupled modes report the coupled loop's count."""
+    rng = np.random.default_rng(4)
+    Z, io = script3_model(rng)
+    G = OA.init_coupled_AOADMM_CMTF(Z, io, rng=rng)
+    _, _, _, out = OA.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=2), init=G)
+    assert list(out['innerIters'][:, 0]) == [5, 1, 1, 5, 5]
+    assert out['exit_flag'] == 'maxIterations'
+    assert out['f_couplings'] > 0 and out['f_constraints'] >= 0
+
+
+def test_exact_coupling_drives_factors_together():
+    rng = np.random.default_rng(5)
+    Z, io = cp_cp_exact_model(rng, noise=0.0)
+    G = OA.init_coupled_AOADMM_CMTF(Z, io, rng=rng)
+    opt = options(MaxOuterIters=400, AbsFuncTol=1e-10, OuterRelTol=1e-9, innerRelPrTol_coupl=1e-4,
+                  innerRelPrTol_constr=1e-4, innerRelDualTol_coupl=1e-4, innerRelDualTol_constr=1e-4)
+    _, Fac, _, out = OA.cmtf_AOADMM(Z, alg_options=opt, init=G)
+    assert out['f_couplings'] < 1e-3
+    assert np.linalg.norm(Fac['fac'][0] - Fac['fac'][3]) / np.linalg.norm(Fac['fac'][0]) < 5e-3
+
+
+def test_stopping_rule_and_exit_flag():
+    o = dict(AbsFuncTol=1e-6, OuterRelTol=1e-3, MaxOuterIters=10)
+    assert OA.evaluate_stopping_conditions((1e-7, 0, 0, 0), (1.0, 0, 0, 0), o)
+    assert not OA.evaluate_stopping_conditions((0.5, 0, 0, 0), (1.0, 0, 0, 0), o)
+    assert OA.evaluate_stopping_conditions((0.9995, 0, 0, 0), (1.0, 0, 0, 0), o)
+    assert OA.make_exit_flag(11, (1, 0, 0, 0), o) == 'maxIterations'
+    fl = OA.make_exit_flag(5, (1e-9, 1.0, 0, 0), o)
+    assert fl['f_tensors'] == 'AbsFuncTol' and fl['f_couplings'] == 'RelFuncTol'
+
+
+def test_not_positive_definite_raises_like_matlab():
+    rng = np.random.default_rng(6)
+    Z, io, _ = cp_model((6, 5, 4), 2, rng, [('non-negativity',)] * 3)
+    G = OA.init_coupled_AOADMM_CMTF(Z, io, rng=rng)
+    G['fac'][1][:] = 0.0          # zero factor => C = 0, rho = 0, B singular => chol throws (:142)
+    with pytest.raises(np.linalg.LinAlgError):
+        OA.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=1), init=G)
