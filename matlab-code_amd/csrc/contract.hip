@@ -105,38 +105,59 @@ __global__ __launch_bounds__(256) void contract_f32(KArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nt][v][i] = 0.f;
 
-  f32x4 xa[4], fa[NT];
-  int64_t g = g0;
-  if (g < gfull) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const f32x4*>(xp + s * ld2);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) fa[nt] = fp[nt * fnt];
+  // Register ring of three stages (8 reduction columns = four 16-byte loads + one B fragment each).
+  // The loads of stage j+2 are issued one at a time BETWEEN the MFMAs of stage j: issuing them as a
+  // burst in front of the 16 MFMAs measured 18 % slower on MI355X (4.7 vs 5.6 TB/s, profiles/README.md),
+  // and without sched_barrier hipcc sinks them down to their first use.
+  f32x4 x0[4], x1[4], x2[4], f0[NT], f1[NT], f2[NT];
+  const int64_t ng = gfull > g0 ? gfull - g0 : 0;
+  const int64_t gstep = kGroup * a.ld;
+#define AO_LOAD_STAGE(XS, FS, GI)                                                                   \
+  {                                                                                                 \
+    const float* p_ = xp + (GI) * gstep;                                                            \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
+      XS[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p_ + s * ld2));             \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) FS[nt] = fp[(GI) * 64 + nt * fnt];            \
   }
-  for (; g < gfull; ++g) {
-    f32x4 xb[4], fb[NT];
-    const float* xn = xp + kGroup * a.ld;
-    const f32x4* fn = fp + 64;
-    if (g + 1 < gfull) {                              // wave-uniform prefetch of the next stage
-#pragma unroll
-      for (int s = 0; s < 4; ++s) xb[s] = *reinterpret_cast<const f32x4*>(xn + s * ld2);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) fb[nt] = fn[nt * fnt];
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          acc[nt][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s][v], fa[nt][s], acc[nt][v], 0, 0, 0);
-    xp = xn;
-    fp = fn;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) xa[s] = xb[s];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) fa[nt] = fb[nt];
+#define AO_COMPUTE_STAGE(XS, FS)                                                                    \
+  {                                                                                                 \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                               \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v)                                                   \
+        acc[nt][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(XS[s][v], FS[nt][s], acc[nt][v], 0, 0, 0); \
   }
+  // consume stage (XC,FC) while fetching stage GI into (XL,FL)
+#define AO_MIX_STAGE(XC, FC, XL, FL, GI)                                                            \
+  {                                                                                                 \
+    const float* p_ = xp + (GI) * gstep;                                                            \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                 \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                             \
+      _Pragma("unroll") for (int v = 0; v < 4; ++v)                                                 \
+          acc[nt][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(XC[s][v], FC[nt][s], acc[nt][v], 0, 0, 0); \
+      XL[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p_ + s * ld2));             \
+      if (s == 3) { _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) FL[nt] = fp[(GI) * 64 + nt * fnt]; } \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+    }                                                                                               \
+  }
+  if (ng > 0) AO_LOAD_STAGE(x0, f0, 0)
+  if (ng > 1) AO_LOAD_STAGE(x1, f1, 1)
+  int64_t g = 0;
+  for (; g + 5 <= ng; g += 3) {                      // steady state: every prefetch is in range
+    AO_MIX_STAGE(x0, f0, x2, f2, g + 2)
+    AO_MIX_STAGE(x1, f1, x0, f0, g + 3)
+    AO_MIX_STAGE(x2, f2, x1, f1, g + 4)
+  }
+  for (; g + 3 <= ng; g += 3) {                      // at most one drained round
+    if (g + 2 < ng) AO_LOAD_STAGE(x2, f2, g + 2)
+    AO_COMPUTE_STAGE(x0, f0)
+    if (g + 3 < ng) AO_LOAD_STAGE(x0, f0, g + 3)
+    AO_COMPUTE_STAGE(x1, f1)
+    if (g + 4 < ng) AO_LOAD_STAGE(x1, f1, g + 4)
+    AO_COMPUTE_STAGE(x2, f2)
+  }
+  if (g < ng) AO_COMPUTE_STAGE(x0, f0)
+  if (g + 1 < ng) AO_COMPUTE_STAGE(x1, f1)
+  g = gfull > g0 ? gfull : g0;
   // ragged tail group: columns >= C are clamped (finite data) and meet zero B fragments
   if (g < g1) {
 #pragma unroll
@@ -144,18 +165,15 @@ __global__ __launch_bounds__(256) void contract_f32(KArgs a) {
       int64_t c = kGroup * g + 2 * s + h;
       if (c >= a.C) c = a.C - 1;
       const float* p = X + b * a.batch_stride + row + c * a.ld;
-      xa[s] = *reinterpret_cast<const f32x4*>(p);
+      x0[s] = *reinterpret_cast<const f32x4*>(p);
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) fa[nt] = (reinterpret_cast<const f32x4*>(a.frag) + g * 64 + lane)[nt * fnt];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          acc[nt][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s][v], fa[nt][s], acc[nt][v], 0, 0, 0);
+    for (int nt = 0; nt < NT; ++nt) f0[nt] = (reinterpret_cast<const f32x4*>(a.frag) + g * 64 + lane)[nt * fnt];
+    AO_COMPUTE_STAGE(x0, f0)
   }
+#undef AO_LOAD_STAGE
+#undef AO_COMPUTE_STAGE
+#undef AO_MIX_STAGE
   // epilogue: C/D map col = lane&31, row rho = (reg&3) + 8*(reg>>2) + 4*(lane>>5); tile row = 4*rho+v
   double* Tc = a.T + ((int64_t)chunk * a.trows + b * a.M) * a.R;
 #pragma unroll
