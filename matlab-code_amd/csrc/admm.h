@@ -18,7 +18,8 @@ size_t prox_ws_bytes(int type, int64_t rows, int R);
 // Z_out = prox(V, rho) for any catalogue entry; rho read from device memory.
 void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, int64_t ldz,
                 int64_t rows, int R, const double* rho_dev, double rho_mul, double* ws,
-                const AdmmCtl* ctl, hipStream_t s);
+                const AdmmCtl* ctl, hipStream_t s, const double* warm = nullptr, int64_t ldw = 0);
+// `warm`: optional previous value of the prox output (same shape); only a speed hint (TV warm start)
 
 // One iteration of ADMM_constrained_only (:608-620) for a CP mode.
 //   fusable prox : fac, Z, mu updated in one row-parallel kernel;
@@ -27,6 +28,7 @@ void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, 
 struct AdmmMode {
   const double* A;      // MTTKRP (+bsum term)            rows x R
   const double* L;      // chol factor                     R x R
+  const double* Binv = nullptr;   // inv(L*L') when available (well-conditioned ADMM systems)
   const double* rho;    // device scalar
   double *fac, *Z, *mu; // rows x R each
   int64_t rows;

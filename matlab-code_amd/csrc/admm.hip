@@ -82,14 +82,14 @@ __device__ __forceinline__ void row_solve_regs2(double (&x)[RMAX], const double*
 }
 
 struct FusedArgs {
-  const double *A, *L, *rho;
+  const double *A, *L, *rho, *Binv;
   double *fac, *Z, *mu, *V, *part;
   int64_t rows;
   int R, fused, ptype;
   double p0, p1;
 };
 
-static constexpr int kRowThreads = 128;
+static constexpr int kRowThreads = 64;
 
 template <int RMAX>
 __global__ __launch_bounds__(kRowThreads) void admm_row_k(FusedArgs a, const AdmmCtl* ctl) {
@@ -97,7 +97,8 @@ __global__ __launch_bounds__(kRowThreads) void admm_row_k(FusedArgs a, const Adm
   extern __shared__ double Lsh[];
   __shared__ double red[4][kRowThreads / 64];
   const int R = a.R;
-  for (int e = threadIdx.x; e < R * R; e += blockDim.x) Lsh[e] = a.L[e];
+  const bool use_inv = a.Binv != nullptr;
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) Lsh[e] = use_inv ? a.Binv[e] : a.L[e];
   __syncthreads();
   const double rho = a.rho[0];
   const double rh = rho / 2;
@@ -116,7 +117,23 @@ __global__ __launch_bounds__(kRowThreads) void admm_row_k(FusedArgs a, const Adm
         x[r] = 0; mu[r] = 0; zo[r] = 0;
       }
     }
-    row_solve_regs2<RMAX>(x, Lsh, R);               // fac = (A_inner/L')/L            (:609)
+    if (use_inv) {                                  // fac = A_inner * inv(L*L')       (:609)
+      double rhs[RMAX];
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) rhs[r] = x[r];
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        if (r < R) {
+          double acc = 0.0;
+#pragma unroll
+          for (int q = 0; q < RMAX; ++q)
+            if (q < R) acc += rhs[q] * Lsh[q + R * r];
+          x[r] = acc;
+        }
+      }
+    } else {
+      row_solve_regs2<RMAX>(x, Lsh, R);             // fac = (A_inner/L')/L            (:609)
+    }
     if (a.fused) {
       double z[RMAX];
 #pragma unroll
@@ -442,6 +459,128 @@ __global__ void prox_tv_k(ColArgs a, int use_lds, const AdmmCtl* ctl) {
   }
 }
 
+// Parallel exact TV prox for one column per 256-thread block (active-set / split-merge form of the
+// same optimality system Condat's scan solves).  With u_i = sum_{t<=i}(y_t - x_t) the minimiser of
+// 0.5||x-y||^2 + lam*sum|x_{i+1}-x_i| is characterised by |u_i| <= lam, u_{n-1} = 0 and
+// u_i = -lam*sign(x_{i+1}-x_i) at every jump.  A guess of the jump set J (signs in {-1,0,+1}) fixes the
+// segment values  v_S = (sum_S y + lam*(J[b] - J[a-1])) / |S| ; jumps whose sign disagrees with
+// v_right - v_left are merged, segments whose interior |u| exceeds lam are split at the worst point.
+// The fixed point satisfies the KKT system, i.e. is the unique minimiser; if the iteration cap is hit
+// thread 0 falls back to the sequential scan, so the result is exact either way.  Inside the ADMM loop
+// J is warm-started from the previous Z column, which usually converges in 1-3 rounds.
+static constexpr int kTvParMax = 4096;
+static constexpr int kTvThreads = 256;
+
+__global__ __launch_bounds__(kTvThreads) void prox_tv_par_k(ColArgs a, const double* warm, int64_t ldw,
+                                                            const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  extern __shared__ double dyn[];
+  __shared__ int scan[kTvThreads];
+  __shared__ int flag_merge, flag_split, nseg_sh;
+  const int n = (int)a.rows;
+  const int t = threadIdx.x;
+  const int r = blockIdx.x;
+  const double* vin = a.V + a.ldv * r;
+  double* z = a.Z + a.ldz * r;
+  const double lam = a.p0 / (a.rho[0] * a.rho_mul);
+  double* y = dyn;                                   // n
+  double* val = dyn + n;                             // n (segment values)
+  int* start = reinterpret_cast<int*>(dyn + 2 * n);  // n + 1
+  signed char* J = reinterpret_cast<signed char*>(start + n + 1);   // n
+  for (int i = t; i < n; i += kTvThreads) y[i] = vin[i];
+  if (!(lam > 0.0)) {
+    __syncthreads();
+    for (int i = t; i < n; i += kTvThreads) z[i] = y[i];
+    return;
+  }
+  if (warm) {
+    const double* w = warm + ldw * r;
+    for (int i = t; i < n - 1; i += kTvThreads) {
+      const double d = w[i + 1] - w[i];
+      J[i] = d > 0 ? 1 : (d < 0 ? -1 : 0);
+    }
+  } else {
+    for (int i = t; i < n - 1; i += kTvThreads) J[i] = 0;
+  }
+  if (t == 0 && n > 0) J[n - 1] = 0;
+  __syncthreads();
+  const int chunk = (n + kTvThreads - 1) / kTvThreads;
+  const int c0 = t * chunk, c1 = min(n, c0 + chunk);
+  const int max_rounds = 4 * n + 64;
+  bool converged = false;
+  for (int round = 0; round < max_rounds; ++round) {
+    // ---- 1. segment starts: i == 0 or a jump between i-1 and i
+    int cnt = 0;
+    for (int i = c0; i < c1; ++i) cnt += (i == 0 || J[i - 1] != 0) ? 1 : 0;
+    scan[t] = cnt;
+    if (t == 0) { flag_merge = 0; flag_split = 0; }
+    __syncthreads();
+    for (int off = 1; off < kTvThreads; off <<= 1) {          // inclusive Hillis-Steele scan
+      const int add = t >= off ? scan[t - off] : 0;
+      __syncthreads();
+      scan[t] += add;
+      __syncthreads();
+    }
+    int pos = scan[t] - cnt;
+    for (int i = c0; i < c1; ++i)
+      if (i == 0 || J[i - 1] != 0) start[pos++] = i;
+    if (t == kTvThreads - 1) { nseg_sh = scan[t]; start[scan[t]] = n; }
+    __syncthreads();
+    const int nseg = nseg_sh;
+    // ---- 2. segment values
+    for (int s = t; s < nseg; s += kTvThreads) {
+      const int sa = start[s], sb = start[s + 1] - 1;
+      double S = 0.0;
+      for (int i = sa; i <= sb; ++i) S += y[i];
+      const double sl = sa == 0 ? 0.0 : (double)J[sa - 1];
+      const double sr = sb == n - 1 ? 0.0 : (double)J[sb];
+      val[s] = (S + lam * (sr - sl)) / (double)(sb - sa + 1);
+    }
+    __syncthreads();
+    // ---- 3. merge jumps whose sign disagrees with the values on both sides
+    for (int s = t; s + 1 < nseg; s += kTvThreads) {
+      const int jp = start[s + 1] - 1;
+      if ((double)J[jp] * (val[s + 1] - val[s]) <= 0.0) { J[jp] = 0; flag_merge = 1; }
+    }
+    __syncthreads();
+    const int merged = flag_merge;
+    __syncthreads();                                   // everyone has read the flag before it is reset
+    if (merged) continue;
+    // ---- 4. split segments whose interior dual leaves [-lam, lam]
+    for (int s = t; s < nseg; s += kTvThreads) {
+      const int sa = start[s], sb = start[s + 1] - 1;
+      const double v = val[s];
+      double u = sa == 0 ? 0.0 : -lam * (double)J[sa - 1];
+      double worst = lam * (1.0 + 1e-13);
+      int widx = -1;
+      double wu = 0.0;
+      for (int i = sa; i < sb; ++i) {
+        u += y[i] - v;
+        const double au = fabs(u);
+        if (au > worst) { worst = au; widx = i; wu = u; }
+      }
+      if (widx >= 0) { J[widx] = wu > 0 ? -1 : 1; flag_split = 1; }
+    }
+    __syncthreads();
+    const int split = flag_split;
+    __syncthreads();
+    if (!split) { converged = true; break; }
+  }
+  if (converged) {
+    const int nseg = nseg_sh;
+    for (int s = t; s < nseg; s += kTvThreads) {
+      const int sa = start[s], sb = start[s + 1] - 1;
+      const double v = val[s];
+      for (int i = sa; i <= sb; ++i) z[i] = v;
+    }
+  } else {
+    __syncthreads();
+    if (t == 0) tv1d_condat_dev(y, val, n, lam);     // exact sequential fallback (val reused as output)
+    __syncthreads();
+    for (int i = t; i < n; i += kTvThreads) z[i] = val[i];
+  }
+}
+
 // isotonic regression (PAVA), non-decreasing; `sign` = -1 gives -project_monotone(-x) (:26,:28)
 __global__ void prox_monotone_k(ColArgs a, double sign, const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
@@ -703,7 +842,7 @@ size_t prox_ws_bytes(int type, int64_t rows, int R) {
 
 void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, int64_t ldz,
                 int64_t rows, int R, const double* rho_dev, double rho_mul, double* ws,
-                const AdmmCtl* ctl, hipStream_t s) {
+                const AdmmCtl* ctl, hipStream_t s, const double* warm, int64_t ldw) {
   ColArgs a;
   a.V = V; a.Z = Zout; a.ldv = ldv; a.ldz = ldz; a.rows = rows; a.R = R; a.type = ps.type;
   a.p0 = ps.p0; a.p1 = ps.p1; a.rho = rho_dev; a.rho_mul = rho_mul; a.ws = ws;
@@ -725,15 +864,24 @@ void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, 
       prox_simplex_col_k<<<R, 256, 0, s>>>(a, ctl);
       break;
     case AOADMM_C_TV: {
+      if (rows <= kTvParMax) {
+        const size_t sh = (size_t)21 * rows + 64;
+        static bool attr_par = false;
+        if (!attr_par) {
+          AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prox_tv_par_k),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(21 * kTvParMax + 64)));
+          attr_par = true;
+        }
+        prox_tv_par_k<<<R, kTvThreads, sh, s>>>(a, warm, ldw, ctl);
+        break;
+      }
       const int use_lds = rows <= kTvLdsRows;
       const size_t sh = use_lds ? (size_t)2 * rows * sizeof(double) : 0;
-      if (sh > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-          AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prox_tv_k),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTvLdsRows * sizeof(double))));
-          attr_set = true;
-        }
+      static bool attr_set = false;
+      if (!attr_set) {
+        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prox_tv_k),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTvLdsRows * sizeof(double))));
+        attr_set = true;
       }
       prox_tv_k<<<R, 64, sh, s>>>(a, use_lds, ctl);
       break;
@@ -756,19 +904,20 @@ void admm_constrained_iteration(const AdmmMode& m, double* part, double* V, doub
                                 AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du,
                                 hipStream_t s) {
   FusedArgs a;
-  a.A = m.A; a.L = m.L; a.rho = m.rho; a.fac = m.fac; a.Z = m.Z; a.mu = m.mu; a.V = V; a.part = part;
+  a.A = m.A; a.L = m.L; a.Binv = m.Binv; a.rho = m.rho; a.fac = m.fac; a.Z = m.Z; a.mu = m.mu; a.V = V; a.part = part;
   a.rows = m.rows; a.R = m.R; a.ptype = m.prox.type; a.p0 = m.prox.p0; a.p1 = m.prox.p1;
   a.fused = prox_is_fusable(m.prox.type) ? 1 : 0;
   const unsigned blocks = (unsigned)cdiv(m.rows, kRowThreads);
   const size_t sh = (size_t)m.R * m.R * sizeof(double);
   if (m.R <= 8) admm_row_k<8><<<blocks, kRowThreads, sh, s>>>(a, ctl);
   else if (m.R <= 16) admm_row_k<16><<<blocks, kRowThreads, sh, s>>>(a, ctl);
+  else if (m.R <= 24) admm_row_k<24><<<blocks, kRowThreads, sh, s>>>(a, ctl);
   else if (m.R <= 32) admm_row_k<32><<<blocks, kRowThreads, sh, s>>>(a, ctl);
   else admm_row_k<64><<<blocks, kRowThreads, sh, s>>>(a, ctl);
   AO_KERNEL_CHECK();
   int nparts = (int)blocks;
   if (!a.fused) {
-    prox_apply(m.prox, V, m.rows, Znew, m.rows, m.rows, m.R, m.rho, 1.0, prox_ws, ctl, s);
+    prox_apply(m.prox, V, m.rows, Znew, m.rows, m.rows, m.R, m.rho, 1.0, prox_ws, ctl, s, m.Z, m.rows);
     int64_t n = m.rows * m.R;
     int64_t nb = cdiv(n, 1024);
     if (nb > 64) nb = 64;
@@ -803,7 +952,7 @@ void constraint_update(const ProxSpec& ps, const double* fac, double* Z, double*
   if (nb > 1024) nb = 1024;
   copy_add_k<<<(unsigned)nb, 256, 0, s>>>(V, Zold, fac, Z, mu, n, ctl);
   AO_KERNEL_CHECK();
-  prox_apply(ps, V, rows, Z, rows, rows, R, rho_dev, rho_mul, prox_ws, ctl, s);   // Z = prox(fac+mu, rho)
+  prox_apply(ps, V, rows, Z, rows, rows, R, rho_dev, rho_mul, prox_ws, ctl, s, Zold, rows);   // Z = prox(fac+mu, rho)
   dual_only_k<<<(unsigned)nb, 256, 0, s>>>(fac, Z, mu, n, ctl);                  // mu += fac - Z
   AO_KERNEL_CHECK();
   sumsq_diff(slots + 0, fac, Z, n, red_ws, ctl, s);

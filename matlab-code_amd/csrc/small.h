@@ -61,6 +61,7 @@ struct SysBuild {
   int nrho;
   int R;
   double *C, *rho, *Bsys, *L;
+  double* Binv = nullptr;   // optional: inv(L*L') (used by the fused ADMM row kernel)
   AdmmCtl* ctl;
 };
 void sys_build(const SysBuild& sb, hipStream_t s);

@@ -76,29 +76,60 @@ void gemm_small(double* out, int64_t ldo, const double* A, int64_t lda, const do
 
 // ---------------------------------------------------------------------------
 // A'B with fixed summation order: block b sums rows [b*rpb, (b+1)*rpb) -> ws[b][K*N]; then one block adds
+static constexpr int kAtbRows = 48;   // rows per block, staged through LDS
 static int atb_blocks(int64_t I) {
-  int64_t nb = cdiv(I, 512);
-  if (nb > 128) nb = 128;
+  int64_t nb = cdiv(I, kAtbRows);
+  if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   return (int)nb;
 }
 size_t atb_ws_bytes(int64_t I, int K, int N) { return (size_t)atb_blocks(I) * K * N * sizeof(double); }
 
+// block b owns rows [b*rpb, (b+1)*rpb): tiles of 64 rows of A and B are staged in LDS (coalesced
+// column reads), every thread accumulates its (k,n) outputs over the tile in a fixed order
 __global__ void atb_part_k(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t I, int K, int N,
                            double* ws, const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
+  extern __shared__ double tile[];           // [kAtbRows][K] then [kAtbRows][N], row-major, padded by 1
+  const int Kp = K + 1, Np = N + 1;
+  double* ta = tile;
+  double* tb = tile + kAtbRows * Kp;
   const int nb = gridDim.x;
   const int64_t rpb = (I + nb - 1) / nb;
   const int64_t i0 = blockIdx.x * rpb;
   int64_t i1 = i0 + rpb;
   if (i1 > I) i1 = I;
-  for (int e = threadIdx.x; e < K * N; e += blockDim.x) {
-    const int k = e % K, n = e / K;
-    const double* a = A + lda * k;
-    const double* b = B + ldb * n;
-    double acc = 0.0;
-    for (int64_t i = i0; i < i1; ++i) acc += a[i] * b[i];
-    ws[(int64_t)blockIdx.x * K * N + e] = acc;
+  const int KN = K * N;
+  double acc[16];                            // K*N <= 4096 = 16 outputs per thread at 256 threads
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+  for (int64_t r0 = i0; r0 < i1; r0 += kAtbRows) {
+    const int nr = (int)((i1 - r0 < kAtbRows) ? (i1 - r0) : kAtbRows);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nr * K; e += blockDim.x) {
+      const int i = e % nr, k = e / nr;
+      ta[i * Kp + k] = A[r0 + i + lda * k];
+    }
+    for (int e = threadIdx.x; e < nr * N; e += blockDim.x) {
+      const int i = e % nr, n = e / nr;
+      tb[i * Np + n] = B[r0 + i + ldb * n];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = threadIdx.x + q * 256;
+      if (e < KN) {
+        const int k = e % K, n = e / K;
+        double a = acc[q];
+        for (int i = 0; i < nr; ++i) a += ta[i * Kp + k] * tb[i * Np + n];
+        acc[q] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int e = threadIdx.x + q * 256;
+    if (e < KN) ws[(int64_t)blockIdx.x * KN + e] = acc[q];
   }
 }
 __global__ void atb_fin_k(double* out, const double* ws, int nb, int KN, const AdmmCtl* ctl) {
@@ -112,7 +143,8 @@ __global__ void atb_fin_k(double* out, const double* ws, int nb, int KN, const A
 void atb_small(double* out, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t I,
                int K, int N, double* ws, const AdmmCtl* ctl, hipStream_t s) {
   const int nb = atb_blocks(I);
-  atb_part_k<<<nb, 256, 0, s>>>(A, lda, B, ldb, I, K, N, ws, ctl);
+  const size_t sh = (size_t)kAtbRows * (K + N + 2) * sizeof(double);
+  atb_part_k<<<nb, 256, sh, s>>>(A, lda, B, ldb, I, K, N, ws, ctl);
   AO_KERNEL_CHECK();
   atb_fin_k<<<1, 256, 0, s>>>(out, ws, nb, K * N, ctl);
   AO_KERNEL_CHECK();
@@ -304,6 +336,25 @@ __global__ void sys_build_k(SysBuild sb) {
   const bool ok = chol_lds(sh, R);               // chol(B','lower') (:142); B symmetric
   if (ok)
     for (int e = threadIdx.x; e < RR; e += blockDim.x) sb.L[e] = sh[e];
+  if (ok && sb.Binv) {
+    // inv(L*L') column by column: forward then backward substitution on e_j.  The system matrix of
+    // an ADMM mode carries +rho/2*I with rho = trace(C)/R, so cond(B) <= 2R+1: the explicit inverse
+    // loses nothing measurable and turns the per-row solve into R independent dot products.
+    for (int j = threadIdx.x; j < R; j += blockDim.x) {
+      double col[kMaxRank];
+      for (int i = 0; i < R; ++i) {
+        double v = (i == j) ? 1.0 : 0.0;
+        for (int q = 0; q < i; ++q) v -= sh[i + R * q] * col[q];
+        col[i] = v / sh[i + R * i];
+      }
+      for (int i = R - 1; i >= 0; --i) {
+        double v = col[i];
+        for (int q = i + 1; q < R; ++q) v -= sh[q + R * i] * col[q];
+        col[i] = v / sh[i + R * i];
+      }
+      for (int i = 0; i < R; ++i) sb.Binv[i + R * j] = col[i];
+    }
+  }
   if (threadIdx.x == 0 && sb.ctl) {
     sb.ctl->active = 1;
     sb.ctl->iters = 0;

@@ -57,7 +57,7 @@ struct ModeInfo {
   int64_t muD_rows = 0, muD_cols = 0;
   uint64_t version = 1;
   // work buffers
-  DevBuf A, Ab, gram, C, Bsys, L, rho, Zold, V, Znew, part, proxws, RHS, TD, tmp;
+  DevBuf A, Ab, gram, C, Bsys, L, Binv, rho, Zold, V, Znew, part, proxws, RHS, TD, tmp;
   const double* Aeff = nullptr;
 };
 

@@ -564,7 +564,7 @@ std::vector<int> Engine::update_sequence(int p) const {
 void Engine::ensure_mode_work(ModeInfo& mi) {
   const size_t nR = (size_t)mi.rows * mi.R * sizeof(double), RR = (size_t)mi.R * mi.R * sizeof(double);
   mi.A.ensure(nR); mi.Ab.ensure(nR);
-  mi.gram.ensure(RR); mi.C.ensure(RR); mi.Bsys.ensure(RR); mi.L.ensure(RR);
+  mi.gram.ensure(RR); mi.C.ensure(RR); mi.Bsys.ensure(RR); mi.L.ensure(RR); mi.Binv.ensure(RR);
   mi.rho.ensure(64);
   mi.Zold.ensure(nR); mi.V.ensure(nR); mi.Znew.ensure(nR); mi.RHS.ensure(nR); mi.TD.ensure(nR); mi.tmp.ensure(nR);
   mi.part.ensure((size_t)admm_partials(mi.rows) * 4 * sizeof(double) + 64 * 4 * sizeof(double));
@@ -598,6 +598,7 @@ void Engine::prepare_mode_system(int m, int nrho, const aoadmm_options& opt) {
   sb.nrho = nrho;
   sb.R = mi.R;
   sb.C = mi.C.d(); sb.rho = mi.rho.d(); sb.Bsys = mi.Bsys.d(); sb.L = mi.L.d();
+  sb.Binv = nrho > 0 ? mi.Binv.d() : nullptr;
   sb.ctl = ctl_of_mode(m);
   sys_build(sb, stream_);
   t.last_pos = mi.pos;                                                        // :121-123
@@ -619,7 +620,7 @@ void Engine::update_uncoupled_cp_mode(int m, const aoadmm_options& opt) {
     row_solve(mi.fac.d(), mi.rows, mi.Aeff, mi.rows, mi.L.d(), mi.rows, mi.R, nullptr, stream_);
   } else {
     AdmmMode am;
-    am.A = mi.Aeff; am.L = mi.L.d(); am.rho = mi.rho.d();
+    am.A = mi.Aeff; am.L = mi.L.d(); am.Binv = mi.Binv.d(); am.rho = mi.rho.d();
     am.fac = mi.fac.d(); am.Z = mi.Z.d(); am.mu = mi.mu.d();
     am.rows = mi.rows; am.R = mi.R; am.prox = mi.prox;
     for (int it = 0; it < opt.MaxInnerIters; ++it)
