@@ -176,9 +176,7 @@ int aoadmm_tensor_upload_rows(aoadmm_ctx* ctx, int p, const double* block, int64
 }
 int aoadmm_par2_slab_upload(aoadmm_ctx* ctx, int p, int k, const double* Xk) {
   CTX_OR_FAIL(ctx);
-  (void)p; (void)k; (void)Xk;
-  g_last_error = "PARAFAC2 blocks are not in the device path yet (use the MATLAB path)";
-  return AOADMM_ERR_UNSUPPORTED;
+  return guarded([&] { ctx->eng->par2_slab_upload(p, k, Xk); });
 }
 int aoadmm_tensor_synth(aoadmm_ctx* ctx, int p, int rank, uint64_t seed, double noise, int precision) {
   CTX_OR_FAIL(ctx);

@@ -1,0 +1,69 @@
+// PARAFAC2 slab kernels (functions/cmtf_fun_AOADMM.m:157-250 block updates, :509-589 ADMM_B_Parafac2,
+// :1247-1268 / :1351-1362 objective pieces).  A PARAFAC2 block is K slabs X_k (I x J_k, ragged J_k);
+// slabs are stored back to back, slab k at element offset I*off[k] (column-major I x J_k); slab-valued
+// factors (B_k, P_k, mu_k, Z_k ...) are stored back to back too, slab k at off[k]*R (column-major J_k x R).
+// All kernels run one workgroup per slab; sizes are small (cfg4: I=40, J_k<=120, R=3, K=256), so these
+// are latency-bound and plain fp64 VALU code.
+#pragma once
+#include "admm.h"
+#include "common.h"
+#include "small.h"
+
+namespace aoadmm {
+
+struct P2Dims {
+  int K, I, R;
+  const int64_t* off;   // device, K+1 prefix sums of J_k
+  const int64_t* off_h; // the same on the host
+  int64_t Jtot;
+  int Jmax;
+};
+
+// T1[k] = X_k * B_k  (I x R each)
+void par2_xkb(const double* X, const double* B, const P2Dims& d, double* T1, hipStream_t s);
+// GB[k] = B_k' * B_k  (R x R each)
+void par2_gram(const double* B, const P2Dims& d, double* GB, hipStream_t s);
+// Amt(i,r) = sum_k T1[k](i,r)*C(k,r) ; Csys(r,q) = sum_k C(k,r)C(k,q)GB[k](r,q)        (:160-165)
+void par2_modeA_combine(const double* T1, const double* Cfac, const double* GB, const P2Dims& d, double* Amt,
+                        double* Csys, hipStream_t s);
+// Ak = w * X_k' * A * D_k  (J_k x R, concatenated)                                       (:193)
+void par2_xta(const double* X, const double* A, const double* Cfac, double w, const P2Dims& d, double* Ak,
+              hipStream_t s);
+// per slab: C_k = D_k GA D_k, rho_k, B_k = w C_k + rho_k/2 (1+constr) I + ridge + bsum/2, L_k = chol   (:194-212)
+void par2_b_system(const double* GA, const double* Cfac, double w, double ridge, double bsum_half, double rho_scale,
+                   int nrho, const P2Dims& d, double* rho, double* L, AdmmCtl* ctl, hipStream_t s);
+
+struct P2BArgs {
+  const double *Ak, *L, *rho;          // rhs, chol factors [K][R*R], rho[K]
+  double *B, *P, *Pold, *mu, *W;       // concatenated J_k x R
+  double *DeltaB, *DeltaBold, *part;   // R x R, R x R, [K][R*R]
+  const double *Z, *muZ;               // constraint variables (nullable)
+  double* norms;                       // [K][8]
+  int use_constr;
+};
+// one inner iteration of ADMM_B_Parafac2 up to (not including) the constraint update   (:525-547, :582-585)
+void par2_b_iteration(const P2BArgs& a, const P2Dims& d, const AdmmCtl* ctl, hipStream_t s);
+// Z_k = prox(B_k + muZ_k, rho_k) ; muZ_k += B_k - Z_k ; norms[k][4..6] = ||B-Z||^2, ||muZ||^2, ||Z-Zold||^2   (:566-579)
+void par2_b_constraint(const ProxSpec& ps, const double* B, double* Z, double* muZ, double* Zold, double* V,
+                       const double* rho, const P2Dims& d, double* prox_ws, double* norms, const AdmmCtl* ctl,
+                       hipStream_t s);
+// residual averages over the slabs + loop condition (:520, :558-585)
+void par2_b_finalize(const double* norms, int K, int use_constr, AdmmCtl* ctl, int max_inner, double tol_pr_coupl,
+                     double tol_pr_constr, double tol_du_coupl, double tol_du_constr, hipStream_t s);
+
+// mode C: a(k,r) = w * sum_i A(i,r) T1[k](i,r) ; C_k = GA .* GB[k] ; rho_k ; B_k (+rho_k/2 I if constrained) ; chol  (:221-240)
+void par2_c_system(const double* A, const double* T1, const double* GA, const double* GB, double w, double ridge,
+                   double bsum_half, int constrained, const P2Dims& d, const double* Cfac, double* a, double* rho,
+                   double* rhomax, double* L, AdmmCtl* ctl, hipStream_t s);
+// row k: rhs = a_k (+ rho_k/2 (Z(k,:) - mu(k,:))) ; C(k,:) = L_k'\(L_k\rhs)      (:236, :604-605)
+void par2_c_rowsolve(const double* a, const double* rho, const double* L, const double* Z, const double* mu,
+                     int use_admm, const P2Dims& d, double* Cfac, const AdmmCtl* ctl, hipStream_t s);
+
+// res[k] = ||X_k - A D_k B_k'||_F^2                                                       (:1262-1264)
+void par2_residual(const double* X, const double* A, const double* B, const double* Cfac, const P2Dims& d,
+                   double* res, hipStream_t s);
+// q[k][0..3] = ||B_k - P_k DeltaB||^2, ||B_k||^2, ||B_k - Z_k||^2 (Z nullable), 0          (:1355, :1337)
+void par2_b_gaps(const double* B, const double* P, const double* DeltaB, const double* Z, const P2Dims& d,
+                 double* q, hipStream_t s);
+
+}  // namespace aoadmm

@@ -1,4 +1,538 @@
-// PARAFAC2 slab kernels (functions/cmtf_fun_AOADMM.m:157-250, :509-589) -- see par2.h.
-#include "common.h"
+// PARAFAC2 slab kernels -- see par2.h.  Reference lines are cited at each kernel.
+#include "par2.h"
+
+#include "device_utils.h"
+
 namespace aoadmm {
+
+#define CTL_GUARD(ctl) \
+  if ((ctl) != nullptr && (ctl)->active == 0) return;
+
+static constexpr int kP2Threads = 64;
+
+// ---------------------------------------------------------------------------
+__global__ void par2_xkb_k(const double* X, const double* B, P2Dims d, double* T1) {
+  const int k = blockIdx.x;
+  const int64_t o = d.off[k];
+  const int Jk = (int)(d.off[k + 1] - o);
+  const double* Xk = X + (int64_t)d.I * o;
+  const double* Bk = B + o * d.R;
+  for (int e = threadIdx.x; e < d.I * d.R; e += blockDim.x) {
+    const int i = e % d.I, r = e / d.I;
+    double acc = 0.0;
+    for (int j = 0; j < Jk; ++j) acc += Xk[i + (int64_t)d.I * j] * Bk[j + Jk * r];
+    T1[(int64_t)k * d.I * d.R + e] = acc;
+  }
+}
+void par2_xkb(const double* X, const double* B, const P2Dims& d, double* T1, hipStream_t s) {
+  par2_xkb_k<<<d.K, 128, 0, s>>>(X, B, d, T1);
+  AO_KERNEL_CHECK();
+}
+
+__global__ void par2_gram_k(const double* B, P2Dims d, double* GB) {
+  const int k = blockIdx.x;
+  const int64_t o = d.off[k];
+  const int Jk = (int)(d.off[k + 1] - o);
+  const double* Bk = B + o * d.R;
+  for (int e = threadIdx.x; e < d.R * d.R; e += blockDim.x) {
+    const int r = e % d.R, q = e / d.R;
+    double acc = 0.0;
+    for (int j = 0; j < Jk; ++j) acc += Bk[j + Jk * r] * Bk[j + Jk * q];
+    GB[(int64_t)k * d.R * d.R + e] = acc;
+  }
+}
+void par2_gram(const double* B, const P2Dims& d, double* GB, hipStream_t s) {
+  par2_gram_k<<<d.K, kP2Threads, 0, s>>>(B, d, GB);
+  AO_KERNEL_CHECK();
+}
+
+// A{m} = sum_k X_k B_k diag(C(k,:)) ; C{m} = sum_k diag(C(k,:)) (B_k'B_k) diag(C(k,:))   (:163-164), k in order
+__global__ void par2_modeA_combine_k(const double* T1, const double* Cfac, const double* GB, P2Dims d, double* Amt,
+                                     double* Csys) {
+  const int nA = d.I * d.R, nC = d.R * d.R;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nA + nC; e += gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    if (e < nA) {
+      const int r = e / d.I;
+      for (int k = 0; k < d.K; ++k) acc += T1[(int64_t)k * nA + e] * Cfac[k + d.K * r];
+      Amt[e] = acc;
+    } else {
+      const int f = e - nA, r = f % d.R, q = f / d.R;
+      for (int k = 0; k < d.K; ++k) acc += Cfac[k + d.K * r] * GB[(int64_t)k * nC + f] * Cfac[k + d.K * q];
+      Csys[f] = acc;
+    }
+  }
+}
+void par2_modeA_combine(const double* T1, const double* Cfac, const double* GB, const P2Dims& d, double* Amt,
+                        double* Csys, hipStream_t s) {
+  const int n = d.I * d.R + d.R * d.R;
+  par2_modeA_combine_k<<<(n + 127) / 128, 128, 0, s>>>(T1, Cfac, GB, d, Amt, Csys);
+  AO_KERNEL_CHECK();
+}
+
+__global__ void par2_xta_k(const double* X, const double* A, const double* Cfac, double w, P2Dims d, double* Ak) {
+  const int k = blockIdx.x;
+  const int64_t o = d.off[k];
+  const int Jk = (int)(d.off[k + 1] - o);
+  const double* Xk = X + (int64_t)d.I * o;
+  double* out = Ak + o * d.R;
+  for (int e = threadIdx.x; e < Jk * d.R; e += blockDim.x) {
+    const int j = e % Jk, r = e / Jk;
+    double acc = 0.0;
+    for (int i = 0; i < d.I; ++i) acc += Xk[i + (int64_t)d.I * j] * A[i + d.I * r];
+    out[e] = w * acc * Cfac[k + d.K * r];           // w * X_k' * A * diag(C(k,:))   (:193)
+  }
+}
+void par2_xta(const double* X, const double* A, const double* Cfac, double w, const P2Dims& d, double* Ak,
+              hipStream_t s) {
+  par2_xta_k<<<d.K, 128, 0, s>>>(X, A, Cfac, w, d, Ak);
+  AO_KERNEL_CHECK();
+}
+
+__global__ void par2_b_system_k(const double* GA, const double* Cfac, double w, double ridge, double bsum_half,
+                                double rho_scale, int nrho, P2Dims d, double* rho, double* L, AdmmCtl* ctl) {
+  extern __shared__ double sh[];
+  __shared__ double rk;
+  const int k = blockIdx.x, R = d.R;
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
+    const int r = e % R, q = e / R;
+    sh[e] = Cfac[k + d.K * r] * GA[e] * Cfac[k + d.K * q];           // C_k = D_k (A'A) D_k   (:194)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int r = 0; r < R; ++r) t += sh[r + R * r];
+    rk = rho_scale * (t / R);                                          // :195-198
+    rho[k] = rk;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
+    double b = w * sh[e];
+    if (e % R == e / R) b += nrho * (rk / 2) + ridge + bsum_half;      // :199-211
+    sh[e] = b;
+  }
+  __syncthreads();
+  const bool ok = chol_lds(sh, R);                                     // chol(B,'lower')  (:212)
+  if (ok)
+    for (int e = threadIdx.x; e < R * R; e += blockDim.x) L[(int64_t)k * R * R + e] = sh[e];
+  else if (threadIdx.x == 0 && ctl) ctl->notpd = 1;
+}
+void par2_b_system(const double* GA, const double* Cfac, double w, double ridge, double bsum_half, double rho_scale,
+                   int nrho, const P2Dims& d, double* rho, double* L, AdmmCtl* ctl, hipStream_t s) {
+  par2_b_system_k<<<d.K, kP2Threads, (size_t)d.R * d.R * sizeof(double), s>>>(GA, Cfac, w, ridge, bsum_half, rho_scale,
+                                                                            nrho, d, rho, L, ctl);
+  AO_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// B-mode inner iteration
+// ---------------------------------------------------------------------------
+// per slab: B_k update (:526-530), W = (B_k + mu_k) * DeltaB' (:532), Pold = P
+__global__ void par2_b_primal_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  extern __shared__ double sh[];          // L_k (R*R) then DeltaB (R*R)
+  const int k = blockIdx.x, R = d.R;
+  const int64_t o = d.off[k];
+  const int Jk = (int)(d.off[k + 1] - o);
+  double* Lsh = sh;
+  double* Dsh = sh + R * R;
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
+    Lsh[e] = a.L[(int64_t)k * R * R + e];
+    Dsh[e] = a.DeltaB[e];
+  }
+  __syncthreads();
+  const double rh = a.rho[k] / 2;
+  const int64_t base = o * R;
+  for (int j = threadIdx.x; j < Jk; j += blockDim.x) {
+    double x[kMaxRank], bm[kMaxRank];
+    for (int r = 0; r < R; ++r) {
+      double pd = 0.0;
+      for (int q = 0; q < R; ++q) pd += a.P[base + j + Jk * q] * Dsh[q + R * r];       // (P_k*DeltaB)(j,r)
+      double v = a.Ak[base + j + Jk * r] + rh * (pd - a.mu[base + j + Jk * r]);
+      if (a.use_constr) v += rh * (a.Z[base + j + Jk * r] - a.muZ[base + j + Jk * r]);    // :527-529
+      x[r] = v;
+    }
+    for (int r = 0; r < R; ++r) {                       // forward: x*L' = rhs
+      double v = x[r];
+      for (int q = 0; q < r; ++q) v -= Lsh[r + R * q] * x[q];
+      x[r] = v / Lsh[r + R * r];
+    }
+    for (int r = R - 1; r >= 0; --r) {                  // backward: x*L = y
+      double v = x[r];
+      for (int q = r + 1; q < R; ++q) v -= Lsh[q + R * r] * x[q];
+      x[r] = v / Lsh[r + R * r];
+    }
+    for (int r = 0; r < R; ++r) {
+      a.B[base + j + Jk * r] = x[r];
+      bm[r] = x[r] + a.mu[base + j + Jk * r];
+      a.Pold[base + j + Jk * r] = a.P[base + j + Jk * r];
+    }
+    for (int r = 0; r < R; ++r) {                       // W(j,r) = sum_q (B+mu)(j,q) * DeltaB(r,q)
+      double v = 0.0;
+      for (int q = 0; q < R; ++q) v += bm[q] * Dsh[r + R * q];
+      a.W[base + j + Jk * r] = v;
+    }
+  }
+}
+
+// P_k = U*V' of svd(W_k,'econ') (:532-534) by one-sided (Hestenes) Jacobi: W*Jrot has orthogonal
+// columns, U = W*Jrot/sigma, V = Jrot.
+__global__ __launch_bounds__(kP2Threads) void par2_polar_k(double* W, double* P, P2Dims d, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  extern __shared__ double Jr[];          // R*R
+  __shared__ double sh[kP2Threads];
+  __shared__ double cs[2];
+  __shared__ int rotated;
+  const int k = blockIdx.x, R = d.R;
+  const int64_t o = d.off[k];
+  const int n = (int)(d.off[k + 1] - o);
+  double* Wk = W + o * R;
+  double* Pk = P + o * R;
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) Jr[e] = (e % R == e / R) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    if (threadIdx.x == 0) rotated = 0;
+    __syncthreads();
+    for (int p = 0; p < R - 1; ++p)
+      for (int q = p + 1; q < R; ++q) {
+        double* wp = Wk + n * p;
+        double* wq = Wk + n * q;
+        double al = 0, be = 0, ga = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) { al += wp[i] * wp[i]; be += wq[i] * wq[i]; ga += wp[i] * wq[i]; }
+        al = block_sum_pow2(al, sh); be = block_sum_pow2(be, sh); ga = block_sum_pow2(ga, sh);
+        if (threadIdx.x == 0) {
+          double c = 1.0, s = 0.0;
+          if (ga != 0.0 && fabs(ga) > 1e-15 * sqrt(al * be)) {
+            const double zeta = (be - al) / (2.0 * ga);
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            c = 1.0 / sqrt(1.0 + t * t);
+            s = c * t;
+            rotated = 1;
+          }
+          cs[0] = c; cs[1] = s;
+        }
+        __syncthreads();
+        const double c = cs[0], s = cs[1];
+        if (s != 0.0) {
+          for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const double x = wp[i], y = wq[i];
+            wp[i] = c * x - s * y;
+            wq[i] = s * x + c * y;
+          }
+          for (int i = threadIdx.x; i < R; i += blockDim.x) {
+            const double x = Jr[i + R * p], y = Jr[i + R * q];
+            Jr[i + R * p] = c * x - s * y;
+            Jr[i + R * q] = s * x + c * y;
+          }
+        }
+        __syncthreads();
+      }
+    const int any = rotated;
+    __syncthreads();
+    if (!any) break;
+  }
+  for (int p = 0; p < R; ++p) {
+    double* wp = Wk + n * p;
+    double al = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) al += wp[i] * wp[i];
+    al = block_sum_pow2(al, sh);
+    const double sg = sqrt(al);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) wp[i] = sg > 0 ? wp[i] / sg : 0.0;
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < n * R; e += blockDim.x) {
+    const int i = e % n, r = e / n;
+    double acc = 0.0;
+    for (int q = 0; q < R; ++q) acc += Wk[i + n * q] * Jr[r + R * q];
+    Pk[e] = acc;
+  }
+}
+
+// part[k] = rho_k * P_k' * (B_k + mu_k)   (:541)
+__global__ void par2_deltab_part_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  const int k = blockIdx.x, R = d.R;
+  const int64_t o = d.off[k];
+  const int Jk = (int)(d.off[k + 1] - o);
+  const int64_t base = o * R;
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
+    const int r = e % R, q = e / R;
+    double acc = 0.0;
+    for (int j = 0; j < Jk; ++j) acc += a.P[base + j + Jk * r] * (a.B[base + j + Jk * q] + a.mu[base + j + Jk * q]);
+    a.part[(int64_t)k * R * R + e] = a.rho[k] * acc;
+  }
+}
+// DeltaB_old = DeltaB ; DeltaB = sum_k part[k] / sum_k rho_k   (:537-544), k in order
+__global__ void par2_deltab_combine_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  const int R = d.R;
+  double sr = 0.0;
+  for (int k = 0; k < d.K; ++k) sr += a.rho[k];
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
+    double acc = 0.0;
+    for (int k = 0; k < d.K; ++k) acc += a.part[(int64_t)k * R * R + e];
+    a.DeltaBold[e] = a.DeltaB[e];
+    a.DeltaB[e] = acc / sr;
+  }
+}
+// mu_k += B_k - P_k*DeltaB (:546); norms[k] = ||B-P*D||^2, ||B||^2, ||Pold*Dold - P*D||^2, ||mu||^2 (:583-584)
+__global__ __launch_bounds__(kP2Threads) void par2_b_dual_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  extern __shared__ double sh2[];         // DeltaB, DeltaBold
+  __shared__ double red[kP2Threads];
+  const int k = blockIdx.x, R = d.R;
+  const int64_t o = d.off[k];
+  const int Jk = (int)(d.off[k + 1] - o);
+  const int64_t base = o * R;
+  double* Dn = sh2;
+  double* Do = sh2 + R * R;
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) { Dn[e] = a.DeltaB[e]; Do[e] = a.DeltaBold[e]; }
+  __syncthreads();
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int e = threadIdx.x; e < Jk * R; e += blockDim.x) {
+    const int j = e % Jk, r = e / Jk;
+    double pd = 0.0, po = 0.0;
+    for (int q = 0; q < R; ++q) {
+      pd += a.P[base + j + Jk * q] * Dn[q + R * r];
+      po += a.Pold[base + j + Jk * q] * Do[q + R * r];
+    }
+    const double b = a.B[base + e];
+    const double m = a.mu[base + e] + b - pd;
+    a.mu[base + e] = m;
+    s0 += (b - pd) * (b - pd); s1 += b * b; s2 += (po - pd) * (po - pd); s3 += m * m;
+  }
+  s0 = block_sum_pow2(s0, red); s1 = block_sum_pow2(s1, red); s2 = block_sum_pow2(s2, red); s3 = block_sum_pow2(s3, red);
+  if (threadIdx.x == 0) {
+    double* nk = a.norms + (int64_t)k * 8;
+    nk[0] = s0; nk[1] = s1; nk[2] = s2; nk[3] = s3;
+  }
+}
+
+void par2_b_iteration(const P2BArgs& a, const P2Dims& d, const AdmmCtl* ctl, hipStream_t s) {
+  const size_t rr = (size_t)d.R * d.R * sizeof(double);
+  par2_b_primal_k<<<d.K, kP2Threads, 2 * rr, s>>>(a, d, ctl);
+  AO_KERNEL_CHECK();
+  par2_polar_k<<<d.K, kP2Threads, rr, s>>>(a.W, a.P, d, ctl);
+  AO_KERNEL_CHECK();
+  par2_deltab_part_k<<<d.K, kP2Threads, 0, s>>>(a, d, ctl);
+  AO_KERNEL_CHECK();
+  par2_deltab_combine_k<<<1, 256, 0, s>>>(a, d, ctl);
+  AO_KERNEL_CHECK();
+  par2_b_dual_k<<<d.K, kP2Threads, 2 * rr, s>>>(a, d, ctl);
+  AO_KERNEL_CHECK();
+}
+
+// ---- constraint on B_k ------------------------------------------------------------------------
+__global__ void par2_bz_pre_k(const double* B, const double* Z, const double* muZ, double* Zold, double* V, int64_t n,
+                              const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    V[i] = B[i] + muZ[i];
+    Zold[i] = Z[i];
+  }
+}
+__global__ __launch_bounds__(kP2Threads) void par2_bz_post_k(const double* B, const double* Z, double* muZ,
+                                                              const double* Zold, P2Dims d, double* norms,
+                                                              const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  __shared__ double red[kP2Threads];
+  const int k = blockIdx.x, R = d.R;
+  const int64_t o = d.off[k];
+  const int Jk = (int)(d.off[k + 1] - o);
+  const int64_t base = o * R;
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int e = threadIdx.x; e < Jk * R; e += blockDim.x) {
+    const double b = B[base + e], z = Z[base + e];
+    const double m = muZ[base + e] + b - z;            // :569
+    muZ[base + e] = m;
+    s0 += (b - z) * (b - z); s1 += m * m; s2 += (Zold[base + e] - z) * (Zold[base + e] - z);
+  }
+  s0 = block_sum_pow2(s0, red); s1 = block_sum_pow2(s1, red); s2 = block_sum_pow2(s2, red);
+  if (threadIdx.x == 0) {
+    double* nk = norms + (int64_t)k * 8;
+    nk[4] = s0; nk[5] = s1; nk[6] = s2;
+  }
+}
+void par2_b_constraint(const ProxSpec& ps, const double* B, double* Z, double* muZ, double* Zold, double* V,
+                       const double* rho, const P2Dims& d, double* prox_ws, double* norms, const AdmmCtl* ctl,
+                       hipStream_t s) {
+  const int64_t n = d.Jtot * d.R;
+  int64_t nb = cdiv(n, 256);
+  if (nb > 1024) nb = 1024;
+  par2_bz_pre_k<<<(unsigned)nb, 256, 0, s>>>(B, Z, muZ, Zold, V, n, ctl);
+  AO_KERNEL_CHECK();
+  // Z_k = prox(B_k + muZ_k, rho_k) slab by slab (:568): every catalogue entry goes through prox_apply
+  const int64_t* off = d.off_h;
+  for (int k = 0; k < d.K; ++k) {
+    const int64_t Jk = off[k + 1] - off[k];
+    prox_apply(ps, V + off[k] * d.R, Jk, Z + off[k] * d.R, Jk, Jk, d.R, rho + k, 1.0, prox_ws, ctl, s,
+               Zold + off[k] * d.R, Jk);
+  }
+  par2_bz_post_k<<<d.K, kP2Threads, 0, s>>>(B, Z, muZ, Zold, d, norms, ctl);
+  AO_KERNEL_CHECK();
+}
+
+__global__ void par2_b_finalize_k(const double* norms, int K, int use_constr, AdmmCtl* ctl, int max_inner,
+                                  double tpc, double tpz, double tdc, double tdz) {
+  if (ctl->active == 0 || threadIdx.x != 0) return;
+  double pc = 0, dc = 0, pz = 0, dz = 0;
+  for (int k = 0; k < K; ++k) {
+    const double* nk = norms + (int64_t)k * 8;
+    const double nb = sqrt(nk[1]);
+    pc += sqrt(nk[0]) / nb / K;                                 // :583
+    dc += sqrt(nk[2]) / sqrt(nk[3]) / K;                        // :584 (no zero check in the reference)
+    if (use_constr) {
+      pz += sqrt(nk[4]) / nb / K;                               // :571
+      const double sc = sqrt(nk[5]);
+      dz += (sc > 0 ? sqrt(nk[6]) / sc : sqrt(nk[6])) / K;       // :572-577
+    }
+  }
+  ctl->res[0] = pc; ctl->res[1] = pz; ctl->res[2] = dc; ctl->res[3] = dz;
+  const int it = ctl->iters + 1;
+  ctl->iters = it;
+  ctl->active = (it < max_inner && (pc > tpc || pz > tpz || dc > tdc || dz > tdz)) ? 1 : 0;   // :520
+}
+void par2_b_finalize(const double* norms, int K, int use_constr, AdmmCtl* ctl, int max_inner, double tol_pr_coupl,
+                     double tol_pr_constr, double tol_du_coupl, double tol_du_constr, hipStream_t s) {
+  par2_b_finalize_k<<<1, 64, 0, s>>>(norms, K, use_constr, ctl, max_inner, tol_pr_coupl, tol_pr_constr, tol_du_coupl,
+                                     tol_du_constr);
+  AO_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// C mode
+// ---------------------------------------------------------------------------
+__global__ void par2_c_system_k(const double* A, const double* T1, const double* GA, const double* GB, double w,
+                                double ridge, double bsum_half, int constrained, P2Dims d, const double* Cfac,
+                                double* a, double* rho, double* L, AdmmCtl* ctl) {
+  extern __shared__ double sh[];
+  __shared__ double rk;
+  const int k = blockIdx.x, R = d.R, I = d.I;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    double acc = 0.0;
+    for (int i = 0; i < I; ++i) acc += A[i + I * r] * T1[(int64_t)k * I * R + i + I * r];
+    a[k + d.K * r] = w * acc + bsum_half * Cfac[k + d.K * r];          // w*diag(A' X_k B_k) (:221), bsum (:231)
+  }
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) sh[e] = GA[e] * GB[(int64_t)k * R * R + e];   // :222
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int r = 0; r < R; ++r) t += sh[r + R * r];
+    rk = t / R;                                                        // :223
+    rho[k] = rk;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
+    double b = w * sh[e];
+    if (e % R == e / R) b += ridge + bsum_half + (constrained ? rk / 2 : 0.0);   // :224-239
+    sh[e] = b;
+  }
+  __syncthreads();
+  const bool ok = chol_lds(sh, R);
+  if (ok)
+    for (int e = threadIdx.x; e < R * R; e += blockDim.x) L[(int64_t)k * R * R + e] = sh[e];
+  else if (threadIdx.x == 0 && ctl) ctl->notpd = 1;
+}
+__global__ void par2_max_k(const double* x, int n, double* out) {
+  if (threadIdx.x == 0) {
+    double m = x[0];
+    for (int i = 1; i < n; ++i) m = fmax(m, x[i]);
+    out[0] = m;                                                        // max(rho)  (:1424)
+  }
+}
+void par2_c_system(const double* A, const double* T1, const double* GA, const double* GB, double w, double ridge,
+                   double bsum_half, int constrained, const P2Dims& d, const double* Cfac, double* a, double* rho,
+                   double* rhomax, double* L, AdmmCtl* ctl, hipStream_t s) {
+  par2_c_system_k<<<d.K, kP2Threads, (size_t)d.R * d.R * sizeof(double), s>>>(A, T1, GA, GB, w, ridge, bsum_half,
+                                                                            constrained, d, Cfac, a, rho, L, ctl);
+  AO_KERNEL_CHECK();
+  par2_max_k<<<1, 64, 0, s>>>(rho, d.K, rhomax);
+  AO_KERNEL_CHECK();
+}
+
+__global__ void par2_c_rowsolve_k(const double* a, const double* rho, const double* L, const double* Z,
+                                  const double* mu, int use_admm, P2Dims d, double* Cfac, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d.K) return;
+  const int R = d.R, K = d.K;
+  const double* Lk = L + (int64_t)k * R * R;
+  double x[kMaxRank];
+  for (int r = 0; r < R; ++r) {
+    double v = a[k + K * r];
+    if (use_admm) v += rho[k] / 2 * (Z[k + K * r] - mu[k + K * r]);             // :604
+    x[r] = v;
+  }
+  for (int r = 0; r < R; ++r) {
+    double v = x[r];
+    for (int q = 0; q < r; ++q) v -= Lk[r + R * q] * x[q];
+    x[r] = v / Lk[r + R * r];
+  }
+  for (int r = R - 1; r >= 0; --r) {
+    double v = x[r];
+    for (int q = r + 1; q < R; ++q) v -= Lk[q + R * r] * x[q];
+    x[r] = v / Lk[r + R * r];
+  }
+  for (int r = 0; r < R; ++r) Cfac[k + K * r] = x[r];                            // :236 / :605
+}
+void par2_c_rowsolve(const double* a, const double* rho, const double* L, const double* Z, const double* mu,
+                     int use_admm, const P2Dims& d, double* Cfac, const AdmmCtl* ctl, hipStream_t s) {
+  par2_c_rowsolve_k<<<(d.K + 63) / 64, 64, 0, s>>>(a, rho, L, Z, mu, use_admm, d, Cfac, ctl);
+  AO_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// objective pieces
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kP2Threads) void par2_residual_k(const double* X, const double* A, const double* B,
+                                                               const double* Cfac, P2Dims d, double* res) {
+  __shared__ double red[kP2Threads];
+  const int k = blockIdx.x, R = d.R, I = d.I;
+  const int64_t o = d.off[k];
+  const int Jk = (int)(d.off[k + 1] - o);
+  const double* Xk = X + (int64_t)I * o;
+  const double* Bk = B + o * R;
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < I * Jk; e += blockDim.x) {
+    const int i = e % I, j = e / I;
+    double m = 0.0;
+    for (int r = 0; r < R; ++r) m += A[i + I * r] * Cfac[k + d.K * r] * Bk[j + Jk * r];
+    const double dlt = Xk[e] - m;
+    acc += dlt * dlt;
+  }
+  acc = block_sum_pow2(acc, red);
+  if (threadIdx.x == 0) res[k] = acc;
+}
+void par2_residual(const double* X, const double* A, const double* B, const double* Cfac, const P2Dims& d,
+                   double* res, hipStream_t s) {
+  par2_residual_k<<<d.K, kP2Threads, 0, s>>>(X, A, B, Cfac, d, res);
+  AO_KERNEL_CHECK();
+}
+
+__global__ __launch_bounds__(kP2Threads) void par2_b_gaps_k(const double* B, const double* P, const double* DeltaB,
+                                                             const double* Z, P2Dims d, double* q) {
+  __shared__ double red[kP2Threads];
+  const int k = blockIdx.x, R = d.R;
+  const int64_t o = d.off[k];
+  const int Jk = (int)(d.off[k + 1] - o);
+  const int64_t base = o * R;
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int e = threadIdx.x; e < Jk * R; e += blockDim.x) {
+    const int j = e % Jk, r = e / Jk;
+    double pd = 0.0;
+    for (int t = 0; t < R; ++t) pd += P[base + j + Jk * t] * DeltaB[t + R * r];
+    const double b = B[base + e];
+    s0 += (b - pd) * (b - pd);
+    s1 += b * b;
+    if (Z) s2 += (b - Z[base + e]) * (b - Z[base + e]);
+  }
+  s0 = block_sum_pow2(s0, red); s1 = block_sum_pow2(s1, red); s2 = block_sum_pow2(s2, red);
+  if (threadIdx.x == 0) { q[(int64_t)k * 4] = s0; q[(int64_t)k * 4 + 1] = s1; q[(int64_t)k * 4 + 2] = s2; q[(int64_t)k * 4 + 3] = 0; }
+}
+void par2_b_gaps(const double* B, const double* P, const double* DeltaB, const double* Z, const P2Dims& d, double* q,
+                 hipStream_t s) {
+  par2_b_gaps_k<<<d.K, kP2Threads, 0, s>>>(B, P, DeltaB, Z, d, q);
+  AO_KERNEL_CHECK();
+}
+
 }  // namespace aoadmm

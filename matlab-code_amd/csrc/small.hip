@@ -1,5 +1,6 @@
 // Small dense fp64 primitives (see small.h).  Reference lines are cited at each kernel.
 #include "small.h"
+#include "device_utils.h"
 
 namespace aoadmm {
 
@@ -269,37 +270,6 @@ void row_solve(double* X, int64_t ldx, const double* RHS, int64_t ldr, const dou
 }
 
 // ---------------------------------------------------------------------------
-// in-LDS Cholesky of a symmetric R x R matrix (column-major), lower factor; returns false if not PD
-__device__ bool chol_lds(double* M, int R) {
-  __shared__ int bad;
-  if (threadIdx.x == 0) bad = 0;
-  __syncthreads();
-  for (int j = 0; j < R; ++j) {
-    if (threadIdx.x == 0) {
-      const double d = M[j + R * j];
-      if (!(d > 0.0)) bad = 1;
-      M[j + R * j] = sqrt(d);
-    }
-    __syncthreads();
-    if (bad) return false;
-    const double djj = M[j + R * j];
-    for (int i = j + 1 + threadIdx.x; i < R; i += blockDim.x) M[i + R * j] /= djj;
-    __syncthreads();
-    const int rem = R - j - 1;
-    for (int e = threadIdx.x; e < rem * rem; e += blockDim.x) {
-      const int i = j + 1 + e % rem, k = j + 1 + e / rem;
-      if (i >= k) M[i + R * k] -= M[i + R * j] * M[k + R * j];
-    }
-    __syncthreads();
-  }
-  for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
-    const int i = e % R, k = e / R;
-    if (i < k) M[e] = 0.0;
-  }
-  __syncthreads();
-  return true;
-}
-
 __global__ void sys_build_k(SysBuild sb) {
   extern __shared__ double sh[];   // R*R
   __shared__ double tr;

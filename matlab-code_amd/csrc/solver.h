@@ -10,6 +10,7 @@
 #include "common.h"
 #include "contract.h"
 #include "misc.h"
+#include "par2.h"
 #include "small.h"
 
 typedef struct ncclComm* ncclComm_t;
@@ -61,9 +62,30 @@ struct ModeInfo {
   const double* Aeff = nullptr;
 };
 
+// PARAFAC2 block: K ragged slabs X_k (I x J_k) and the block's internal coupling variables
+struct Par2Block {
+  int K = 0, I = 0, R = 0;
+  std::vector<int64_t> off_h;     // K+1 prefix sums of J_k
+  DevBuf off_d;
+  int64_t Jtot = 0;
+  int Jmax = 0;
+  DevBuf X;                       // slabs back to back, fp64
+  std::vector<char> have_slab;
+  DevBuf DeltaB, DeltaBold, P, Pold, muDB;        // state (G.DeltaB, G.P, G.mu_DeltaB)
+  bool has_DeltaB = false;
+  std::vector<char> have_P, have_mu;
+  DevBuf W, T1, GB, Ak, Lk, rhok, part, norms, res, q, Csys, ac, Lc, rhoc, rhomax;
+  P2Dims dims() const {
+    P2Dims d;
+    d.K = K; d.I = I; d.R = R; d.off = off_d.as<int64_t>(); d.off_h = off_h.data(); d.Jtot = Jtot; d.Jmax = Jmax;
+    return d;
+  }
+};
+
 struct TensorInfo {
   bool defined = false;
   bool par2 = false;
+  Par2Block p2;
   int nmodes = 0;
   int modes[8] = {0};
   double weight = 1.0;
@@ -108,6 +130,7 @@ class Engine {
   // data
   void tensor_upload(int p, const double* data, int prec, int64_t row0, int64_t local_rows);
   void tensor_synth(int p, int rank, uint64_t seed, double noise, int prec);
+  void par2_slab_upload(int p, int k, const double* Xk);
   double tensor_normsq(int p);
 
   // state
@@ -144,6 +167,13 @@ class Engine {
   void coupled_admm(int c, const aoadmm_options& opt);
   void eval_objective_enqueue(bool first);
   void ensure_mode_work(ModeInfo& mi);
+  // PARAFAC2 (solver_par2.hip)
+  void par2_ensure_work(TensorInfo& t);
+  void par2_prepare_modeA(int m, int nrho, const aoadmm_options& opt);
+  void par2_update_B(int m, const aoadmm_options& opt, int iter);
+  void par2_update_C(int m, const aoadmm_options& opt);
+  void par2_objective_enqueue(TensorInfo& t);
+  double* resid_slots(int m);
   std::vector<int> update_sequence(int p) const;
 
   int device_ = 0;

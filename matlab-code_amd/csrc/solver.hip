@@ -117,11 +117,6 @@ void Engine::add_cp(int p, int n, const int* modes, double weight) {
   }
 }
 
-void Engine::add_par2(int p, const int* modes3, double weight) {
-  (void)p; (void)modes3; (void)weight;
-  throw Error(AOADMM_ERR_UNSUPPORTED, "PARAFAC2 blocks are not in the device path yet (use the MATLAB path)");
-}
-
 void Engine::set_constraint(int mode, int type, const double* params, int np, const double* Lmat) {
   check_mode(mode);
   ModeInfo& mi = modes_[mode];
@@ -178,6 +173,20 @@ void Engine::model_end() {
     AO_REQUIRE(modes_[m].tensor >= 0, "mode %d belongs to no tensor (Mismatch between size and modes inputs)", m);
   }
   for (int p = 0; p < n_tensors_; ++p) AO_REQUIRE(tensors_[p].defined, "tensor %d undefined", p);
+  for (int m = 0; m < n_modes_; ++m) {
+    const ModeInfo& mi = modes_[m];
+    if (!tensors_[mi.tensor].par2) continue;
+    if (mi.pos == 1) {
+      // check_data_input.m:33-35
+      AO_REQUIRE(mi.coupling < 0, "Coupling in 2. mode (the varying mode) of Parafac2 decomposition not supported.");
+      const int ty = mi.prox.type;
+      if (mi.constrained && (ty == AOADMM_C_L1_REG || ty == AOADMM_C_L0_REG || ty == AOADMM_C_L2_REG ||
+                             ty == AOADMM_C_RIDGE || ty == AOADMM_C_GL_SMOOTH || ty == AOADMM_C_TV))
+        throw Error(AOADMM_ERR_UNSUPPORTED, "regularisation-type constraints on the PARAFAC2 B_k mode are not in the device path yet");
+    }
+    if (mi.pos == 2 && mi.coupling >= 0)
+      throw Error(AOADMM_ERR_UNSUPPORTED, "coupling of the PARAFAC2 C mode is not in the device path yet (use the MATLAB path)");
+  }
   for (int c = 0; c < n_couplings_; ++c) {
     CouplingInfo& ci = couplings_[c];
     AO_REQUIRE(ci.type >= 0, "coupling %d has no type (Mismatch between number of couplings and coupling types)", c);
@@ -299,8 +308,12 @@ double Engine::tensor_normsq(int p) {
     DevBuf ws;
     ws.alloc(1024 * sizeof(double) + 64);
     double* slot = slots_.d() + n_modes_ * (kSlotsPerMode + kResidPerMode) + 2 * n_tensors_;
-    tensor_sumsq(slot, t.blk.X.data.p, t.blk.X.prec, t.blk.X.elems_padded(), ws.d(), stream_);
-    allreduce(slot, 1);
+    if (t.par2) {   // sum_k ||X_k||_F^2  (cmtf_AOADMM.m:145-155)
+      tensor_sumsq(slot, t.p2.X.p, AOADMM_PREC_F64, (int64_t)t.p2.I * t.p2.Jtot, ws.d(), stream_);
+    } else {
+      tensor_sumsq(slot, t.blk.X.data.p, t.blk.X.prec, t.blk.X.elems_padded(), ws.d(), stream_);
+      allreduce(slot, 1);
+    }
     double v = 0;
     AO_HIP(hipMemcpyAsync(&v, slot, sizeof(double), hipMemcpyDeviceToHost, stream_));
     AO_HIP(hipStreamSynchronize(stream_));
@@ -354,77 +367,122 @@ void Engine::tensor_synth(int p, int rank, uint64_t seed, double noise, int prec
 // ---------------------------------------------------------------------------
 // state
 // ---------------------------------------------------------------------------
+// Resolve a field of the struct G to its device location.  Slab-valued fields (PARAFAC2 B mode and the
+// block's P / mu_DeltaB) live back to back; `slab` selects J_k x R block k.
+struct StateLoc {
+  double* p;
+  int64_t rows, cols;
+};
+static StateLoc slab_loc(DevBuf& buf, const ModeInfo& mB, int slab) {
+  AO_REQUIRE(slab >= 0 && slab < mB.K, "slab %d out of range [0,%d)", slab, mB.K);
+  buf.ensure((size_t)mB.rows * mB.R * sizeof(double));
+  return StateLoc{buf.d() + mB.off_k[slab] * mB.R, mB.rows_k[slab], (int64_t)mB.R};
+}
+
 void Engine::state_set(int field, int index, int slab, const double* host, int64_t rows, int64_t cols) {
   AO_REQUIRE(model_done_, "call aoadmm_model_end first");
   AO_REQUIRE(host != nullptr && rows > 0 && cols > 0, "state_set: empty array");
   AO_HIP(hipSetDevice(device_));
-  (void)slab;
-  auto put = [&](DevBuf& b) {
-    b.ensure((size_t)rows * cols * sizeof(double));
-    AO_HIP(hipMemcpyAsync(b.p, host, (size_t)rows * cols * sizeof(double), hipMemcpyHostToDevice, stream_));
-    AO_HIP(hipStreamSynchronize(stream_));
-  };
+  StateLoc loc{nullptr, 0, 0};
   if (field == AOADMM_F_COUPLING_FAC) {
     AO_REQUIRE(index >= 0 && index < n_couplings_, "coupling %d out of range", index);
     CouplingInfo& ci = couplings_[index];
-    AO_REQUIRE(rows == ci.rows && cols == ci.cols, "coupling_fac{%d} must be %lld x %lld", index + 1, (long long)ci.rows, (long long)ci.cols);
-    put(ci.Delta);
+    ci.Delta.ensure((size_t)ci.rows * ci.cols * sizeof(double));
+    loc = StateLoc{ci.Delta.d(), ci.rows, ci.cols};
     ci.has_state = true;
-    return;
+  } else if (field == AOADMM_F_DELTAB || field == AOADMM_F_P || field == AOADMM_F_MU_DELTAB) {
+    AO_REQUIRE(index >= 0 && index < n_tensors_ && tensors_[index].par2, "tensor %d is not a PARAFAC2 block", index);
+    TensorInfo& t = tensors_[index];
+    Par2Block& b = t.p2;
+    const ModeInfo& mB = modes_[t.modes[1]];
+    if (field == AOADMM_F_DELTAB) {
+      b.DeltaB.ensure((size_t)b.R * b.R * sizeof(double));
+      loc = StateLoc{b.DeltaB.d(), (int64_t)b.R, (int64_t)b.R};
+      b.has_DeltaB = true;
+    } else if (field == AOADMM_F_P) {
+      loc = slab_loc(b.P, mB, slab);
+      b.have_P[slab] = 1;
+    } else {
+      loc = slab_loc(b.muDB, mB, slab);
+      b.have_mu[slab] = 1;
+    }
+  } else {
+    check_mode(index);
+    ModeInfo& mi = modes_[index];
+    auto whole = [&](DevBuf& buf, int64_t r, int64_t c) {
+      buf.ensure((size_t)r * c * sizeof(double));
+      return StateLoc{buf.d(), r, c};
+    };
+    switch (field) {
+      case AOADMM_F_FAC:
+        loc = mi.slabs ? slab_loc(mi.fac, mi, slab) : whole(mi.fac, mi.rows, mi.R);
+        mi.has_fac = true; mi.version++;
+        break;
+      case AOADMM_F_CONSTRAINT_FAC:
+        loc = mi.slabs ? slab_loc(mi.Z, mi, slab) : whole(mi.Z, mi.rows, mi.R);
+        mi.has_Z = true;
+        break;
+      case AOADMM_F_CONSTRAINT_DUAL:
+        loc = mi.slabs ? slab_loc(mi.mu, mi, slab) : whole(mi.mu, mi.rows, mi.R);
+        mi.has_mu = true;
+        break;
+      case AOADMM_F_COUPLING_DUAL:
+        AO_REQUIRE(!mi.slabs, "the PARAFAC2 B_k mode cannot be coupled");
+        loc = whole(mi.muD, rows, cols);
+        mi.has_muD = true; mi.muD_rows = rows; mi.muD_cols = cols;
+        break;
+      default: throw Error(AOADMM_ERR_INVALID, fmt("unknown state field %d", field));
+    }
   }
-  if (field == AOADMM_F_DELTAB || field == AOADMM_F_P || field == AOADMM_F_MU_DELTAB)
-    throw Error(AOADMM_ERR_UNSUPPORTED, "PARAFAC2 state is not in the device path yet");
-  check_mode(index);
-  ModeInfo& mi = modes_[index];
-  AO_REQUIRE(!mi.slabs, "slab-valued mode state is not in the device path yet");
-  switch (field) {
-    case AOADMM_F_FAC:
-      AO_REQUIRE(rows == mi.rows && cols == mi.R, "fac{%d} must be %lld x %d", index + 1, (long long)mi.rows, mi.R);
-      put(mi.fac); mi.has_fac = true; mi.version++;
-      break;
-    case AOADMM_F_CONSTRAINT_FAC:
-      AO_REQUIRE(rows == mi.rows && cols == mi.R, "constraint_fac{%d} has the wrong size", index + 1);
-      put(mi.Z); mi.has_Z = true;
-      break;
-    case AOADMM_F_CONSTRAINT_DUAL:
-      AO_REQUIRE(rows == mi.rows && cols == mi.R, "constraint_dual_fac{%d} has the wrong size", index + 1);
-      put(mi.mu); mi.has_mu = true;
-      break;
-    case AOADMM_F_COUPLING_DUAL:
-      put(mi.muD); mi.has_muD = true; mi.muD_rows = rows; mi.muD_cols = cols;
-      break;
-    default: throw Error(AOADMM_ERR_INVALID, fmt("unknown state field %d", field));
-  }
+  AO_REQUIRE(rows == loc.rows && cols == loc.cols, "state field %d index %d slab %d must be %lld x %lld, got %lld x %lld", field,
+             index + 1, slab + 1, (long long)loc.rows, (long long)loc.cols, (long long)rows, (long long)cols);
+  AO_HIP(hipMemcpyAsync(loc.p, host, (size_t)rows * cols * sizeof(double), hipMemcpyHostToDevice, stream_));
+  AO_HIP(hipStreamSynchronize(stream_));
 }
 
 void Engine::state_get(int field, int index, int slab, double* host, int64_t rows, int64_t cols) {
   AO_REQUIRE(host != nullptr, "state_get: null destination");
   AO_HIP(hipSetDevice(device_));
-  (void)slab;
-  const DevBuf* src = nullptr;
-  int64_t r = 0, c = 0;
+  StateLoc loc{nullptr, 0, 0};
   if (field == AOADMM_F_COUPLING_FAC) {
     AO_REQUIRE(index >= 0 && index < n_couplings_, "coupling %d out of range", index);
-    src = &couplings_[index].Delta; r = couplings_[index].rows; c = couplings_[index].cols;
     AO_REQUIRE(couplings_[index].has_state, "coupling_fac{%d} was never set", index + 1);
+    loc = StateLoc{couplings_[index].Delta.d(), couplings_[index].rows, couplings_[index].cols};
+  } else if (field == AOADMM_F_DELTAB || field == AOADMM_F_P || field == AOADMM_F_MU_DELTAB) {
+    AO_REQUIRE(index >= 0 && index < n_tensors_ && tensors_[index].par2, "tensor %d is not a PARAFAC2 block", index);
+    TensorInfo& t = tensors_[index];
+    Par2Block& b = t.p2;
+    const ModeInfo& mB = modes_[t.modes[1]];
+    AO_REQUIRE(b.has_DeltaB, "DeltaB{%d} was never set", index + 1);
+    if (field == AOADMM_F_DELTAB) loc = StateLoc{b.DeltaB.d(), (int64_t)b.R, (int64_t)b.R};
+    else if (field == AOADMM_F_P) loc = slab_loc(b.P, mB, slab);
+    else loc = slab_loc(b.muDB, mB, slab);
   } else {
     check_mode(index);
     ModeInfo& mi = modes_[index];
-    r = mi.rows; c = mi.R;
     switch (field) {
-      case AOADMM_F_FAC: src = &mi.fac; AO_REQUIRE(mi.has_fac, "fac{%d} was never set", index + 1); break;
-      case AOADMM_F_CONSTRAINT_FAC: src = &mi.Z; AO_REQUIRE(mi.has_Z, "constraint_fac{%d} was never set", index + 1); break;
-      case AOADMM_F_CONSTRAINT_DUAL: src = &mi.mu; AO_REQUIRE(mi.has_mu, "constraint_dual_fac{%d} was never set", index + 1); break;
+      case AOADMM_F_FAC:
+        AO_REQUIRE(mi.has_fac, "fac{%d} was never set", index + 1);
+        loc = mi.slabs ? slab_loc(mi.fac, mi, slab) : StateLoc{mi.fac.d(), mi.rows, (int64_t)mi.R};
+        break;
+      case AOADMM_F_CONSTRAINT_FAC:
+        AO_REQUIRE(mi.has_Z, "constraint_fac{%d} was never set", index + 1);
+        loc = mi.slabs ? slab_loc(mi.Z, mi, slab) : StateLoc{mi.Z.d(), mi.rows, (int64_t)mi.R};
+        break;
+      case AOADMM_F_CONSTRAINT_DUAL:
+        AO_REQUIRE(mi.has_mu, "constraint_dual_fac{%d} was never set", index + 1);
+        loc = mi.slabs ? slab_loc(mi.mu, mi, slab) : StateLoc{mi.mu.d(), mi.rows, (int64_t)mi.R};
+        break;
       case AOADMM_F_COUPLING_DUAL:
-        src = &mi.muD; r = mi.muD_rows; c = mi.muD_cols;
         AO_REQUIRE(mi.has_muD, "coupling_dual_fac{%d} was never set", index + 1);
+        loc = StateLoc{mi.muD.d(), mi.muD_rows, mi.muD_cols};
         break;
       default: throw Error(AOADMM_ERR_UNSUPPORTED, fmt("state field %d not available", field));
     }
   }
-  AO_REQUIRE(rows == r && cols == c, "state_get: destination is %lld x %lld, field is %lld x %lld", (long long)rows,
-             (long long)cols, (long long)r, (long long)c);
-  AO_HIP(hipMemcpyAsync(host, src->p, (size_t)r * c * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  AO_REQUIRE(rows == loc.rows && cols == loc.cols, "state_get: destination is %lld x %lld, field is %lld x %lld", (long long)rows,
+             (long long)cols, (long long)loc.rows, (long long)loc.cols);
+  AO_HIP(hipMemcpyAsync(host, loc.p, (size_t)rows * cols * sizeof(double), hipMemcpyDeviceToHost, stream_));
   AO_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -579,6 +637,11 @@ void Engine::compute_gram(ModeInfo& mi) {
 void Engine::prepare_mode_system(int m, int nrho, const aoadmm_options& opt) {
   ModeInfo& mi = modes_[m];
   TensorInfo& t = tensors_[mi.tensor];
+  if (t.par2) {                      // first PARAFAC2 mode: same system, different A and C (:159-178)
+    AO_REQUIRE(mi.pos == 0, "internal: only the first PARAFAC2 mode goes through the CP-style system");
+    par2_prepare_modeA(m, nrho, opt);
+    return;
+  }
   FactorRef facs[8];
   for (int i = 0; i < t.nmodes; ++i) {
     const ModeInfo& o = modes_[t.modes[i]];
@@ -783,6 +846,16 @@ void Engine::eval_objective_enqueue(bool first) {
   double* S = slots_.d();
   for (int p = 0; p < n_tensors_; ++p) {
     TensorInfo& t = tensors_[p];
+    if (t.par2) {
+      par2_objective_enqueue(t);                 // direct residual (:1262-1264) + internal-coupling gaps (:1355)
+      if (!first && t.last_pos == 0) {           // shortcut through last_mttkrp / last_had (:1254-1260)
+        ModeInfo& lm = modes_[t.modes[0]];
+        double* sp = S + n_modes_ * kSlotsPerMode + 2 * p;
+        dot(sp + 0, lm.A.d(), lm.fac.d(), lm.rows * lm.R, redws_.d(), nullptr, stream_);
+        dot(sp + 1, lm.C.d(), lm.gram.d(), (int64_t)lm.R * lm.R, redws_.d(), nullptr, stream_);
+      }
+      continue;
+    }
     if (first) {
       // cp_func.m:47-55 / pca_func.m:29-39: same formula with the first mode's MTTKRP
       ModeInfo& m0 = modes_[t.modes[0]];
@@ -808,6 +881,7 @@ void Engine::eval_objective_enqueue(bool first) {
   }
   for (int m = 0; m < n_modes_; ++m) {
     ModeInfo& mi = modes_[m];
+    if (mi.slabs) continue;                      // per-slab ratios come from par2_b_gaps
     double* sm = S + (int64_t)m * kSlotsPerMode;
     const int64_t nm = mi.rows * mi.R;
     sumsq_diff(sm + 0, mi.fac.d(), nullptr, nm, redws_.d(), nullptr, stream_);
@@ -850,13 +924,24 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
       AO_REQUIRE(couplings_[mi.coupling].has_state, "G.coupling_fac{%d} missing", mi.coupling + 1);
     }
     ensure_mode_work(mi);
-    compute_gram(mi);                                                        // :62-81
+    if (!mi.slabs) compute_gram(mi);                                         // :62-81
+  }
+  for (int p = 0; p < n_tensors_; ++p) {
+    TensorInfo& t = tensors_[p];
+    if (!t.par2) continue;
+    Par2Block& b = t.p2;
+    AO_REQUIRE(b.has_DeltaB, "G.DeltaB{%d} missing", p + 1);
+    for (int k = 0; k < b.K; ++k) AO_REQUIRE(b.have_P[k] && b.have_mu[k], "G.P{%d}{%d} / G.mu_DeltaB{%d}{%d} missing", p + 1, k + 1, p + 1, k + 1);
+    par2_ensure_work(t);
+    par2_gram(modes_[t.modes[1]].fac.d(), b.dims(), b.GB.d(), stream_);      // :71-73
+    t.last_pos = 2;
   }
   const int nctl = n_modes_ + n_couplings_;
   std::vector<AdmmCtl> hctl(nctl);
   const int nslots = n_modes_ * kSlotsPerMode + 2 * n_tensors_;
   std::vector<double> hs(nslots);
 
+  bool eval_first = true;
   auto finish_eval = [&](double f[4]) {
     AO_HIP(hipMemcpyAsync(hs.data(), slots_.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream_));
     AO_HIP(hipMemcpyAsync(hctl.data(), ctls_.p, nctl * sizeof(AdmmCtl), hipMemcpyDeviceToHost, stream_));
@@ -864,17 +949,49 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     for (int i = 0; i < nctl; ++i)
       if (hctl[i].notpd)
         throw Error(AOADMM_ERR_NOT_PD, "Cholesky failed: system matrix is not positive definite (chol in cmtf_fun_AOADMM.m:142/273/362)");
-    double ft = 0.0;
+    double ft = 0.0, fpar = 0.0, fcon = 0.0;
+    int ncon = 0;
     for (int p = 0; p < n_tensors_; ++p) {
-      const TensorInfo& t = tensors_[p];
+      TensorInfo& t = tensors_[p];
       const double* sp = hs.data() + n_modes_ * kSlotsPerMode + 2 * p;
-      const double f2 = sp[0] / t.weight;                                     // last_mttkrp = A*1/w (:121)
-      ft += t.weight * (t.normsq - 2.0 * f2 + sp[1]);                          // :1235-1241
+      if (t.par2) {
+        Par2Block& b = t.p2;
+        std::vector<double> res(b.K), q((size_t)b.K * 4);
+        AO_HIP(hipMemcpyAsync(res.data(), b.res.p, b.K * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        AO_HIP(hipMemcpyAsync(q.data(), b.q.p, (size_t)b.K * 4 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        AO_HIP(hipStreamSynchronize(stream_));
+        double fp = 0.0;
+        if (!eval_first && t.last_pos == 0) fp = t.normsq - 2.0 * (sp[0] / t.weight) + sp[1];   // :1254-1260
+        else for (int k = 0; k < b.K; ++k) fp += res[k];                                        // :1262-1264
+        ft += t.weight * fp;                                                                    // :1267
+        const ModeInfo& mB = modes_[t.modes[1]];
+        double gp = 0.0, gz = 0.0, nb2 = 0.0;
+        for (int k = 0; k < b.K; ++k) {
+          const double nb = std::sqrt(q[4 * k + 1]);
+          gp += std::sqrt(q[4 * k]) / nb;                                                       // :1355
+          gz += std::sqrt(q[4 * k + 2]) / nb;                                                   // :1337
+          nb2 += q[4 * k + 1];
+        }
+        fpar += gp;
+        if (mB.constrained) {
+          const double g = gz / b.K;                                                            // :1339
+          fcon += g;
+          if (g != 0.0) ++ncon;
+          if (has_ridge_) ft += mB.ridge * nb2;                                                 // :1292-1295 (quirk: only if constrained)
+        }
+      } else {
+        const double f2 = sp[0] / t.weight;                                   // last_mttkrp = A*1/w (:121)
+        ft += t.weight * (t.normsq - 2.0 * f2 + sp[1]);                        // :1235-1241
+      }
     }
-    double fcon = 0.0; int ncon = 0;
+    if (fpar > 0) {                                                            // :1360-1362 (quirk: K of the LAST tensor)
+      const TensorInfo& tl = tensors_[n_tensors_ - 1];
+      fpar /= tl.par2 ? tl.p2.K : 1;
+    }
     std::vector<double> cp(n_couplings_, 0.0);
     for (int m = 0; m < n_modes_; ++m) {
       const ModeInfo& mi = modes_[m];
+      if (mi.slabs) continue;
       const double* sm = hs.data() + (int64_t)m * kSlotsPerMode;
       const double nf = std::sqrt(sm[0]);
       if (mi.constrained) {
@@ -893,12 +1010,13 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     for (double v : cp) { fc += v; if (v != 0.0) ++nc; }
     if (fc > 0) fc /= nc;                                                      // :1327-1329
     if (fcon > 0) fcon /= ncon;                                                // :1346-1348
-    f[0] = ft; f[1] = fc; f[2] = fcon; f[3] = 0.0;
+    f[0] = ft; f[1] = fc; f[2] = fcon; f[3] = fpar;
   };
 
   double f[4], fo[4];
   eval_objective_enqueue(true);                                                // :32
   finish_eval(f);
+  eval_first = false;
   if (out->func_val_conv) out->func_val_conv[0] = f[0];
   if (out->func_coupl_conv) out->func_coupl_conv[0] = f[1];
   if (out->func_constr_conv) out->func_constr_conv[0] = f[2];
@@ -919,7 +1037,10 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
       for (int p : ps)                                                         // :91
         for (int m : cm)                                                       // :93
           if (modes_[m].tensor == p) {
-            if (cid < 0) update_uncoupled_cp_mode(m, opt);
+            const bool par2 = tensors_[p].par2;
+            if (par2 && modes_[m].pos == 1) par2_update_B(m, opt, iter);             // :191-218
+            else if (par2 && modes_[m].pos == 2) par2_update_C(m, opt);              // :219-248
+            else if (cid < 0) update_uncoupled_cp_mode(m, opt);
             else prepare_mode_system(m, 1 + (modes_[m].constrained ? 1 : 0), opt);   // :269-273 / :358-362
           }
       if (cid >= 0) {
@@ -941,6 +1062,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
         const ModeInfo& mi = modes_[m];
         double v;
         if (mi.coupling >= 0) v = hctl[n_modes_ + mi.coupling].iters;          // :392
+        else if (mi.slabs) v = hctl[m].iters;                                  // :215
         else if (mi.constrained) v = hctl[m].iters;                            // :146
         else v = 1;                                                            // :138
         out->innerIters[(int64_t)(iter - 1) * n_modes_ + m] = v;

@@ -88,3 +88,66 @@ def cp_cp_exact_model(rng, noise=0.05):
     distr = [lambda a, b: rng.random((a, b))] * 6
     io = dict(lambdas_init=[[1] * R, [1] * R], nvecs=0, distr=distr, normalize=1)
     return Z, io
+
+
+def par2_slabs(I, Jk, R, rng, noise=0.0, nonneg_C=True):
+    """PARAFAC2 data X_k = A diag(C_k) B_k' with B_k = P_k*DeltaB, P_k orthonormal
+    (create_irregularPARAFAC2_coupled_data.m shape family), normalised to sum ||X_k||^2 = 1."""
+    K = len(Jk)
+    A = rng.standard_normal((I, R))
+    C = rng.random((K, R)) + 0.1 if nonneg_C else rng.standard_normal((K, R))
+    DB = rng.standard_normal((R, R))
+    X = []
+    for k in range(K):
+        Q, _ = np.linalg.qr(rng.standard_normal((Jk[k], R)))
+        Xk = A @ np.diag(C[k]) @ (Q @ DB).T
+        if noise > 0:
+            N = rng.standard_normal(Xk.shape)
+            Xk = Xk + noise * np.linalg.norm(Xk) / np.linalg.norm(N) * N
+        X.append(Xk)
+    nrm = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in X))
+    return [x / nrm for x in X], A
+
+
+def script4_model(rng, K=12, noise=0.2, constraints_B=None):
+    """example_script4_irregularPAR2.m:18-51: PARAFAC2 I=40, ragged J_k from 61..120, R=3, C non-negative."""
+    I, R = 40, 3
+    Jk = [61 + (7 * k) % 60 for k in range(K)]
+    X, _ = par2_slabs(I, Jk, R, rng, noise)
+    Z = dict(loss_function=['Frobenius'], model=['PAR2'], modes=[[1, 2, 3]], size=[I, Jk, K],
+             coupling=dict(lin_coupled_modes=[0, 0, 0], coupling_type=[], coupl_trafo_matrices=[None] * 3),
+             constrained_modes=[0, 1 if constraints_B else 0, 1], constraints=[None, constraints_B, ('non-negativity',)],
+             weights=[1.0], object=[X])
+    distr = [lambda a, b: rng.standard_normal((a, b)), lambda a, b: rng.standard_normal((a, b)),
+             lambda a, b: rng.random((a, b)) + 0.1]
+    io = dict(lambdas_init=[[1] * R], nvecs=0, distr=distr, normalize=1)
+    return Z, io
+
+
+def script1_model(rng, dims=(20, 30, 40), K=20, Jk=30, noise=0.0):
+    """example_script1_CP_PAR2_nonneg.m:21-44: CP tensor + PARAFAC2 (I equal, K slabs) sharing their first
+    factor exactly (modes 1 and 4, coupling type 0); non-negativity on modes 1,2,3,4,6."""
+    R = 3
+    I = dims[0]
+    A = rng.random((I, R))
+    X1 = full_ktensor([A, rng.random((dims[1], R)), rng.random((dims[2], R))])
+    if noise > 0:
+        N = rng.standard_normal(X1.shape)
+        X1 = X1 + noise * np.linalg.norm(X1) / np.linalg.norm(N) * N
+    X1 /= np.linalg.norm(X1)
+    C = rng.random((K, R)) + 0.1
+    DB = rng.standard_normal((R, R))
+    Xk = []
+    for k in range(K):
+        Q, _ = np.linalg.qr(rng.standard_normal((Jk, R)))
+        Xk.append(A @ np.diag(C[k]) @ (Q @ DB).T)
+    nrm = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in Xk))
+    Xk = [x / nrm for x in Xk]
+    Z = dict(loss_function=['Frobenius'] * 2, model=['CP', 'PAR2'], modes=[[1, 2, 3], [4, 5, 6]],
+             size=[dims[0], dims[1], dims[2], I, [Jk] * K, K],
+             coupling=dict(lin_coupled_modes=[1, 0, 0, 1, 0, 0], coupling_type=[0], coupl_trafo_matrices=[None] * 6),
+             constrained_modes=[1, 1, 1, 1, 0, 1],
+             constraints=[('non-negativity',)] * 4 + [None, ('non-negativity',)], weights=[0.5, 0.5], object=[X1, Xk])
+    distr = [lambda a, b: rng.random((a, b))] * 4 + [lambda a, b: rng.standard_normal((a, b)), lambda a, b: rng.random((a, b))]
+    io = dict(lambdas_init=[[1] * R, [1] * R], nvecs=0, distr=distr, normalize=1)
+    return Z, io

@@ -89,3 +89,49 @@ def test_fp32_tensor_mode(pkg, eng):
     Fo, oo, Fg, og = run_both(pkg, eng, Z, io, options(MaxOuterIters=10), precision='f32')
     for a, b in zip(Fo['fac'], Fg['fac']):
         assert rel_fro(b, a) < 1e-4
+
+
+def compare_par2(Fo, oo, Fg, og, tol=TOL):
+    def each(a, b, key):
+        if a is None:
+            return
+        if isinstance(a, (list, tuple)):
+            for x, y in zip(a, b):
+                each(x, y, key)
+        elif isinstance(a, dict):
+            for k in a:
+                each(a[k], b[k], key)
+        else:
+            assert rel_fro(b, a) < tol, (key, rel_fro(b, a))
+    for key in ('fac', 'constraint_fac', 'constraint_dual_fac', 'coupling_fac', 'coupling_dual_fac', 'DeltaB', 'P', 'mu_DeltaB'):
+        each(Fo[key], Fg[key], key)
+    assert og['OuterIterations'] == oo['OuterIterations']
+    assert np.array_equal(og['innerIters'], oo['innerIters'])
+    for k in ('func_val_conv', 'func_coupl_conv', 'func_constr_conv', 'func_PAR2_coupl'):
+        assert np.allclose(og[k], oo[k], rtol=1e-7, atol=1e-10), (k, og[k], oo[k])
+
+
+def test_script4_irregular_parafac2(pkg, eng):
+    """config 4 family (example_script4: I=40, ragged J_k in 61..120, R=3, C non-negative), K = 12 slabs."""
+    from helpers import script4_model
+    rng = np.random.default_rng(10)
+    Z, io = script4_model(rng, K=12)
+    compare_par2(*run_both(pkg, eng, Z, io, options(MaxOuterIters=12)))
+
+
+def test_parafac2_constrained_Bk(pkg, eng):
+    """B_k constrained (example_script9 family: unimodality on the B_k columns, delayed start, rho factor)."""
+    from helpers import script4_model
+    rng = np.random.default_rng(11)
+    Z, io = script4_model(rng, K=6, constraints_B=('unimodality', False))
+    opt = options(MaxOuterIters=8, iter_start_PAR2Bkconstraint=3, increase_factor_rhoBk=2.0)
+    compare_par2(*run_both(pkg, eng, Z, io, opt))
+
+
+@pytest.mark.parametrize('dims', [(20, 30, 40), (40, 50, 60)])
+def test_script1_cp_parafac2_coupled(pkg, eng, dims):
+    """config 1 (example_script1: CP + PARAFAC2, first modes exactly coupled, non-negativity), both shape readings."""
+    from helpers import script1_model
+    rng = np.random.default_rng(12)
+    Z, io = script1_model(rng, dims=dims)
+    compare_par2(*run_both(pkg, eng, Z, io, options(MaxOuterIters=10)))
