@@ -1,0 +1,102 @@
+"""GPU: BASELINE.json's full-size configurations.  Where the oracle finishes in seconds it is the checker
+(configs 2 and 4); at 2000^3 (config 5) size-independent properties of the MTTKRP are used instead."""
+import copy
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import aoadmm as OA
+from helpers import options, rel_fro
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config2_500cube_rank10_fp64(pkg, eng):
+    """config 2: single CP 500x500x500, R = 10, non-negativity, fp64 tensor; 2 outer iterations vs the oracle, 1e-8."""
+    rng = np.random.default_rng(20)
+    n, R = 500, 10
+    A = [rng.random((n, R)) for _ in range(3)]
+    X = np.einsum('ir,jr,kr->ijk', *A, optimize=True)
+    X += 0.05 * np.linalg.norm(X) / np.sqrt(X.size) * rng.standard_normal(X.shape)
+    X /= np.linalg.norm(X)
+    X = np.asfortranarray(X)
+    Z = dict(loss_function=['Frobenius'], model=['CP'], modes=[[1, 2, 3]], size=[n, n, n],
+             coupling=dict(lin_coupled_modes=[0, 0, 0], coupling_type=[], coupl_trafo_matrices=[None] * 3),
+             constrained_modes=[1, 1, 1], constraints=[('non-negativity',)] * 3, weights=[1.0], object=[X])
+    io = dict(lambdas_init=[[1] * R], nvecs=0, distr=[lambda a, b: rng.random((a, b))] * 3, normalize=1)
+    G = OA.init_coupled_AOADMM_CMTF(Z, io, rng=rng)
+    opt = options(MaxOuterIters=2)
+    _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
+    _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=eng, precision='f64')
+    for a, b in zip(Fo['fac'], Fg['fac']):
+        assert rel_fro(b, a) < 1e-8
+    assert np.allclose(og['func_val_conv'], oo['func_val_conv'], rtol=1e-8)
+
+
+def test_config4_parafac2_256_slabs(pkg, eng):
+    """config 4: irregular PARAFAC2, I = 40, R = 3, K = 256 slabs with J_k cycled over 61..120, C non-negative."""
+    from helpers import script4_model
+    from test_gpu_solver import compare_par2, run_both
+    rng = np.random.default_rng(21)
+    Z, io = script4_model(rng, K=256)
+    compare_par2(*run_both(pkg, eng, Z, io, options(MaxOuterIters=5)))
+
+
+def test_config5_2000cube_mttkrp_inner_product_identity(pkg, eng):
+    """config 5 size (2000^3, R = 20, fp32 tensor generated in HBM): for any factors,
+    sum(mttkrp_n .* U_n) = <X, [[U_1,U_2,U_3]]> must be the same number for n = 1,2,3 and per column r --
+    three different kernels paths (two contraction layouts, two reductions) have to agree.  Tolerance 2e-5
+    relative (fp32 products, fp32 accumulation over 2000 terms, fp64 above)."""
+    capi = importlib.import_module('matlab-code_amd._capi')
+    n, R = 2000, 20
+    Z = dict(loss_function=['Frobenius'], model=['CP'], modes=[[1, 2, 3]], size=[n] * 3,
+             coupling=dict(lin_coupled_modes=[0, 0, 0], coupling_type=[], coupl_trafo_matrices=[None] * 3),
+             constrained_modes=[0, 0, 0], constraints=[None] * 3, weights=[1.0],
+             object=[dict(synthetic=True, rank=R, seed=3, noise=0.05)], _ranks=[R] * 3)
+    pkg.build_model(eng, Z, 'f32')
+    nsq = C.c_double()
+    capi.check(eng.lib.aoadmm_tensor_normsq(eng.h, 0, C.byref(nsq)))
+    assert abs(nsq.value - 1.0) < 1e-5                      # the generator normalises ||X|| = 1
+    rng = np.random.default_rng(22)
+    U = [rng.standard_normal((n, R)) for _ in range(3)]
+    pkg.upload_state(eng, Z, dict(fac=U))
+    sums = []
+    for pos in range(3):
+        out = np.zeros((n, R), order='F')
+        capi.check(eng.lib.aoadmm_resident_mttkrp(eng.h, 0, pos, capi.dptr(out), None))
+        sums.append(np.sum(out * U[pos], axis=0))
+    scale = np.max(np.abs(sums[0]))
+    assert np.max(np.abs(sums[0] - sums[1])) < 2e-5 * scale
+    assert np.max(np.abs(sums[0] - sums[2])) < 2e-5 * scale
+    # linearity in one factor (size independent): mttkrp(X,[U1, 2*U2 - V2, U3],1) = 2*m(U2) - m(V2)
+    V2 = rng.standard_normal((n, R))
+    outs = []
+    for F2 in (U[1], V2, 2 * U[1] - V2):
+        pkg.upload_state(eng, Z, dict(fac=[U[0], F2, U[2]]))
+        o = np.zeros((n, R), order='F')
+        capi.check(eng.lib.aoadmm_resident_mttkrp(eng.h, 0, 0, capi.dptr(o), None))
+        outs.append(o)
+    assert rel_fro(outs[2], 2 * outs[0] - outs[1]) < 2e-5
+    # release the 32 GB tensor held by the session engine
+    small = dict(Z, size=[4, 4, 4], object=[np.zeros((4, 4, 4))], _ranks=[2] * 3)
+    pkg.build_model(eng, small, 'f64')
+
+
+def test_dimension_tree_reuse_changes_nothing(pkg, eng):
+    """Cached partial contractions (2 tensor reads / iteration) give the same factors as recomputing every
+    mode's contraction (3 reads).  With the cache, mode 1 is sometimes finished from the middle-mode
+    contraction instead of the last-mode one, so sums differ in order only: 1e-12."""
+    from helpers import cp_model
+    rng = np.random.default_rng(23)
+    Z, io, _ = cp_model((48, 40, 36), 4, rng, [('non-negativity',)] * 3)
+    G = OA.init_coupled_AOADMM_CMTF(Z, io, rng=rng)
+    outs = []
+    for flag in (1, 0):
+        opt = options(MaxOuterIters=6)
+        opt['hip'] = dict(use_dimtree=flag)
+        _, F, _, o = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=eng)
+        outs.append(F)
+    for a, b in zip(outs[0]['fac'], outs[1]['fac']):
+        assert rel_fro(a, b) < 1e-12
