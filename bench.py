@@ -167,6 +167,15 @@ def main():
         bytes_per_launch = by.value / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         flops_mttkrp = 2.0 * I * J * K * R
+        # HBM bytes per launch from the PMC pass committed under profiles/ (separate rocprofv3 --pmc runs,
+        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for this exact workload
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_contract_f32.json')
+        if world == 1 and args.size == 2000 and R == 20 and args.prec == 'f32' and os.path.exists(pmc):
+            try:
+                traffic = float(json.load(open(pmc))['hbm_traffic_bytes_per_launch'])
+            except Exception:
+                traffic = None
         line = {
             'metric': 'AO-ADMM outer iters/sec (+ mode-1 MTTKRP GFLOP/s), %d^3 rank-%d CP' % (args.size, R),
             'value': args.steps / dt, 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -183,11 +192,11 @@ def main():
             'datagen_s': t_gen,
             'roofline': {'bound': 'hbm', 'kernel': 'contract_%s (tensor x factor partial contraction)' % args.prec,
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'avg_launch_ms': avg_ms, 'launches': launches,
+                         'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': launches,
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'note': 'per rank; bytes = local tensor block (s_X) + T written (8*R per unfolding row)'},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             try:
                 line['cpu_baseline'] = cpu_baseline(J, K, R, min(args.cpu_rows, I), I)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number

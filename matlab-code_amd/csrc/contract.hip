@@ -19,6 +19,8 @@
 //      A[row l&15][k=l>>4]; a double2 load gives rows 2*(l&15)+v.
 #include "contract.h"
 
+#include <cstdlib>
+
 namespace aoadmm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -76,7 +78,7 @@ struct KArgs {
   int groups_per_chunk, R;
 };
 
-template <int NT>
+template <int NT, int SP>
 __global__ __launch_bounds__(256) void contract_f32(KArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t wt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -130,13 +132,17 @@ __global__ __launch_bounds__(256) void contract_f32(KArgs a) {
 #define AO_MIX_STAGE(XC, FC, XL, FL, GI)                                                            \
   {                                                                                                 \
     const float* p_ = xp + (GI) * gstep;                                                            \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                 \
+    _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                \
       _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                             \
-      _Pragma("unroll") for (int v = 0; v < 4; ++v)                                                 \
-          acc[nt][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(XC[s][v], FC[nt][s], acc[nt][v], 0, 0, 0); \
-      XL[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p_ + s * ld2));             \
-      if (s == 3) { _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) FL[nt] = fp[(GI) * 64 + nt * fnt]; } \
-      __builtin_amdgcn_sched_barrier(0);                                                            \
+        acc[nt][q & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(XC[q >> 2][q & 3], FC[nt][q >> 2], acc[nt][q & 3], 0, 0, 0); \
+      if ((q + 1) % SP == 0) {                                                                      \
+        const int li = (q + 1) / SP - 1;                                                            \
+        if (li < 4) XL[li] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p_ + li * ld2)); \
+        if (li == 4 || (SP == 4 && li == 3)) {                                                      \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) FL[nt] = fp[(GI) * 64 + nt * fnt];      \
+        }                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+      }                                                                                             \
     }                                                                                               \
   }
   if (ng > 0) AO_LOAD_STAGE(x0, f0, 0)
@@ -331,8 +337,11 @@ void launch_contract(const void* X, int prec, const ContractPlan& pl, const doub
     pack_frag_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (float*)frag_ws);
     AO_KERNEL_CHECK();
     if (ev0) AO_HIP(hipEventRecord(ev0, s));
-    if (NT == 1) contract_f32<1><<<grid, 256, 0, s>>>(a);
-    else if (NT == 2) contract_f32<2><<<grid, 256, 0, s>>>(a);
+    static const int sp = getenv("AOADMM_CONTRACT_SP") ? atoi(getenv("AOADMM_CONTRACT_SP")) : 4;
+    if (NT == 1 && sp == 3) contract_f32<1, 3><<<grid, 256, 0, s>>>(a);
+    else if (NT == 1 && sp == 2) contract_f32<1, 2><<<grid, 256, 0, s>>>(a);
+    else if (NT == 1) contract_f32<1, 4><<<grid, 256, 0, s>>>(a);
+    else if (NT == 2) contract_f32<2, 4><<<grid, 256, 0, s>>>(a);
     else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
   } else {
     AO_REQUIRE(pl.ld % 2 == 0 && pl.M % 2 == 0 && pl.batch_stride % 2 == 0, "f64 layout must be padded to 2");

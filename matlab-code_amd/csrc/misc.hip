@@ -64,6 +64,18 @@ __device__ __forceinline__ double block_reduce256(double v, double* sh) {
   return r;
 }
 
+__device__ __forceinline__ double block_reduce_n(double v, double* sh) {   // blockDim.x a power of two
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int st = blockDim.x >> 1; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
 template <typename T>
 __global__ void tensor_sumsq_k(double* ws, const T* X, int64_t n) {
   __shared__ double sh[256];
@@ -197,8 +209,8 @@ void synth_write(void* X, int prec, const double* A, const double* B, const doub
 
 // ---------------------------------------------------------------------------
 // regulariser values: constraints_to_prox.m:49,53,57,61,77,81
-__global__ void reg_value_k(double* slot, int type, double eta, const double* X, int64_t rows, int R) {
-  __shared__ double sh[256];
+__global__ __launch_bounds__(1024) void reg_value_k(double* slot, int type, double eta, const double* X, int64_t rows, int R) {
+  __shared__ double sh[1024];
   double acc = 0.0;
   const int64_t n = rows * R;
   if (type == AOADMM_C_L2_REG) {
@@ -206,7 +218,7 @@ __global__ void reg_value_k(double* slot, int type, double eta, const double* X,
     for (int r = 0; r < R; ++r) {
       double a = 0.0;
       for (int64_t i = threadIdx.x; i < rows; i += blockDim.x) { const double v = X[i + rows * r]; a += v * v; }
-      tot += sqrt(block_reduce256(a, sh));
+      tot += sqrt(block_reduce_n(a, sh));
     }
     if (threadIdx.x == 0) slot[0] = eta * tot;
     return;
@@ -223,13 +235,13 @@ __global__ void reg_value_k(double* slot, int type, double eta, const double* X,
       default: break;
     }
   }
-  const double t = block_reduce256(acc, sh);
+  const double t = block_reduce_n(acc, sh);
   if (threadIdx.x == 0) slot[0] = eta * t;
 }
 void reg_value(double* slot, int type, double p0, const double* X, int64_t rows, int R, double* ws,
                hipStream_t s) {
   (void)ws;
-  reg_value_k<<<1, 256, 0, s>>>(slot, type, p0, X, rows, R);
+  reg_value_k<<<1, 1024, 0, s>>>(slot, type, p0, X, rows, R);
   AO_KERNEL_CHECK();
 }
 
