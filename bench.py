@@ -135,13 +135,16 @@ def main():
     if args.warmup > 0:
         pkg.run_solver(eng, opts(args.warmup), 3)
     ms = C.c_double(); nl = C.c_int64(); by = C.c_double(); fl = C.c_double()
-    capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 1, C.byref(ms), C.byref(nl), C.byref(by), C.byref(fl)))
+    ms1 = C.c_double(); nl1 = C.c_int64(); by1 = C.c_double(); fl1 = C.c_double()
+    capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 0, 1, C.byref(ms), C.byref(nl), C.byref(by), C.byref(fl)))
+    capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 1, 1, C.byref(ms1), C.byref(nl1), C.byref(by1), C.byref(fl1)))
     barrier()
     t0 = time.perf_counter()
     out = pkg.run_solver(eng, opts(args.steps), 3)
     barrier()
     dt = time.perf_counter() - t0
-    capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 1, C.byref(ms), C.byref(nl), C.byref(by), C.byref(fl)))
+    capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 0, 1, C.byref(ms), C.byref(nl), C.byref(by), C.byref(fl)))
+    capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 1, 1, C.byref(ms1), C.byref(nl1), C.byref(by1), C.byref(fl1)))
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -158,7 +161,7 @@ def main():
         tt = torch.tensor([mttkrp_ms], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         mttkrp_ms = float(tt.item())
-    capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 1, None, None, None, None))
+    capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 0, 1, None, None, None, None))
 
     if rank == 0:
         sx = 4.0 if args.prec == 'f32' else 8.0
@@ -184,7 +187,7 @@ def main():
             'config': {'workload': 'cfg5: %dx%dx%d R=%d CP, mode1 TV(0.001), modes2-3 nonneg, %s tensor + fp64 solve, '
                                    'MaxInnerIters=5, tol=0' % (I, J, K, R, args.prec),
                        'sharding': 'mode-1 rows over %d GPU(s), factors replicated' % world,
-                       'tensor_passes_per_iter': round(launches / args.steps, 2)},
+                       'tensor_passes_per_iter': round((launches + int(nl1.value)) / args.steps, 2)},
             'mttkrp_mode1_gflops': flops_mttkrp / (mttkrp_ms * 1e-3) / 1e9,
             'mttkrp_mode1_ms': mttkrp_ms,
             'mttkrp_mfma_frac_f32_peak': flops_mttkrp / (mttkrp_ms * 1e-3) / 1e12 / (F32_MFMA_PEAK_TF * world),
@@ -195,6 +198,10 @@ def main():
                          'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': launches,
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'note': 'per rank; bytes = local tensor block (s_X) + T written (8*R per unfolding row)'},
+            'second_kernel': {'kernel': 'contract_lead_f32 (leading-mode contraction, LDS-transposed; 1 of 3 tensor passes)',
+                              'launches': int(nl1.value),
+                              'avg_launch_ms': (ms1.value / nl1.value) if nl1.value else None,
+                              'achieved_GBps': (by1.value / nl1.value / (ms1.value / nl1.value * 1e-3) / 1e9) if nl1.value and ms1.value > 0 else None},
         }
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
             try:

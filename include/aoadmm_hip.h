@@ -187,8 +187,10 @@ int aoadmm_solve(aoadmm_ctx* ctx, const aoadmm_options* opt, aoadmm_result* out)
  * result stays on the device; elapsed device time of the kernels is returned */
 int aoadmm_resident_mttkrp(aoadmm_ctx* ctx, int p, int tensor_mode, double* out_host_or_null,
                            float* elapsed_ms);
-/* device-time (ms) and launch count of the dominant contraction kernel since the last reset */
-int aoadmm_kernel_stats(aoadmm_ctx* ctx, int reset, double* contract_ms, int64_t* contract_launches,
+/* device time (ms, HIP events on the library's stream around the kernel only), launch count, algorithmic
+ * bytes and flops of a tensor-pass kernel since the last reset.  which = 0: register-streaming contraction
+ * (contract_f32/f64, trailing modes); which = 1: LDS-transposed leading-mode contraction (contract_lead_f32) */
+int aoadmm_kernel_stats(aoadmm_ctx* ctx, int which, int reset, double* contract_ms, int64_t* contract_launches,
                         double* contract_bytes, double* contract_flops);
 
 /* ---- op level (host in / host out) -------------------------------------- */

@@ -112,7 +112,7 @@ def load_library():
     lib.aoadmm_state_get.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, i64, i64]
     lib.aoadmm_solve.argtypes = [vp, C.POINTER(Options), C.POINTER(Result)]
     lib.aoadmm_resident_mttkrp.argtypes = [vp, C.c_int, C.c_int, dp, C.POINTER(C.c_float)]
-    lib.aoadmm_kernel_stats.argtypes = [vp, C.c_int, dp, C.POINTER(i64), dp, dp]
+    lib.aoadmm_kernel_stats.argtypes = [vp, C.c_int, C.c_int, dp, C.POINTER(i64), dp, dp]
     lib.aoadmm_op_mttkrp.argtypes = [vp, dp, C.c_int, C.POINTER(i64), C.POINTER(dp), C.c_int, C.c_int, C.c_int, dp]
     lib.aoadmm_op_gram.argtypes = [vp, dp, i64, C.c_int, dp]
     lib.aoadmm_op_chol.argtypes = [vp, dp, C.c_int, dp]

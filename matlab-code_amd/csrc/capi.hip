@@ -211,10 +211,10 @@ int aoadmm_resident_mttkrp(aoadmm_ctx* ctx, int p, int tensor_mode, double* out_
   CTX_OR_FAIL(ctx);
   return guarded([&] { ctx->eng->resident_mttkrp(p, tensor_mode, out_host_or_null, elapsed_ms); });
 }
-int aoadmm_kernel_stats(aoadmm_ctx* ctx, int reset, double* contract_ms, int64_t* contract_launches,
+int aoadmm_kernel_stats(aoadmm_ctx* ctx, int which, int reset, double* contract_ms, int64_t* contract_launches,
                         double* contract_bytes, double* contract_flops) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->kernel_stats(reset, contract_ms, contract_launches, contract_bytes, contract_flops); });
+  return guarded([&] { ctx->eng->kernel_stats(which, reset, contract_ms, contract_launches, contract_bytes, contract_flops); });
 }
 
 // ---------------------------------------------------------------------------

@@ -28,6 +28,7 @@ struct ContractPlan {
   int64_t nbatch, batch_stride, M, ld, C;
   int R;
   int nchunk;          // split of the reduction (bounds f32 accumulation length)
+  bool lead = false;   // true: the contracted mode is the contiguous one (X[c + ld*m]), LDS-transposed kernel
   int64_t trows() const { return nbatch * M; }
   size_t t_bytes() const { return (size_t)nchunk * trows() * R * sizeof(double); }
   size_t frag_bytes(int prec) const;
@@ -39,6 +40,9 @@ struct ContractPlan {
 
 ContractPlan make_plan(int64_t nbatch, int64_t batch_stride, int64_t M, int64_t ld, int64_t C, int R,
                        int prec);
+
+// T(m,r) = sum_c X[c + ld*m] * F(c,r): contraction of the leading (contiguous) mode, fp32 tensors
+ContractPlan make_lead_plan(int64_t M, int64_t ld, int64_t C, int R);
 
 // F: device fp64, column-major (C x R) with leading dimension ldF.
 void launch_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,

@@ -199,6 +199,149 @@ __global__ __launch_bounds__(256) void contract_f32(KArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// f32 contraction of the LEADING (contiguous) mode:  T(m, r) = sum_i X[i + ld*m] * F(i, r)
+// ---------------------------------------------------------------------------
+// Here the reduction index is the contiguous one, so MFMA A operands (one unfolding row per lane)
+// cannot be loaded straight from HBM: a workgroup streams a [128 rows m] x [64 i] tile (128 segments
+// of 256 contiguous bytes) through registers into LDS (row stride 68 floats: ds_read_b128 of 16 rows at
+// one column offset hits 16 distinct 16-byte slots), and each wave feeds its 32 rows to
+// v_mfma_f32_32x32x2_f32 from ds_read_b128 (4 consecutive i per lane = 4 MFMA k-steps).  The loads of
+// chunk c+1 are in flight while chunk c is consumed; one barrier per chunk (double-buffered LDS).
+// B fragments are packed so that lane (h, col) finds F[8g + 4h + t][col] for t = 0..3 in one float4.
+static constexpr int kLeadRows = 128;   // unfolding rows per workgroup
+static constexpr int kLeadKC = 64;      // reduction elements per chunk
+static constexpr int kLeadStride = 68;  // LDS row stride in floats
+
+__global__ void pack_frag_lead_f32(const double* __restrict__ F, int64_t ldF, int64_t C, int R, int NT,
+                                   int64_t Cg, float* __restrict__ frag) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over nt*Cg*64*4
+  int64_t total = (int64_t)NT * Cg * 256;
+  if (idx >= total) return;
+  int t = idx & 3;
+  int lane = (idx >> 2) & 63;
+  int64_t g = (idx >> 8) % Cg;
+  int nt = (int)((idx >> 8) / Cg);
+  int64_t c = 8 * g + 4 * (lane >> 5) + t;
+  int r = 32 * nt + (lane & 31);
+  float v = 0.f;
+  if (c < C && r < R) v = (float)F[c + ldF * r];
+  frag[idx] = v;
+}
+
+struct LArgs {
+  const float* X;
+  const float* frag;
+  double* T;
+  int64_t M, ld, C, Cg;      // rows of the unfolding, row stride, reduction length, groups of 8
+  int chunks_per_slice;      // 64-element chunks per accumulation slice (blockIdx.y)
+  int R;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void contract_lead_f32(LArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][kLeadRows][kLeadStride]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * kLeadRows;
+  const int slice = blockIdx.y;
+  const int64_t nchunks_total = (a.C + kLeadKC - 1) / kLeadKC;
+  const int64_t c0 = (int64_t)slice * a.chunks_per_slice;
+  int64_t c1 = c0 + a.chunks_per_slice;
+  if (c1 > nchunks_total) c1 = nchunks_total;
+  // staging map: 8 x 16-byte loads per thread, thread -> (row = (tid>>4) + 16q, 4 floats at 4*(tid&15))
+  const int srow = tid >> 4, scol = 4 * (tid & 15);
+  const float* rowp[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    int64_t m = m0 + srow + 16 * q;
+    if (m >= a.M) m = a.M - 1;                       // tail tile: re-read a valid row, never stored
+    rowp[q] = a.X + m * a.ld;
+  }
+  const int64_t last4 = a.ld - 4;                    // last 16-byte aligned group inside a row
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+  const int r32 = lane & 31, h = lane >> 5;
+  const f32x4* fbase = reinterpret_cast<const f32x4*>(a.frag) + lane;
+  const int64_t fnt = a.Cg * 64;
+  // two register sets: while chunk k is consumed from LDS, chunk k+1 sits in one set (written to the
+  // other LDS buffer first) and chunks k+2 / k+3 are in flight -- one 16-byte load issued per 4 MFMAs
+  f32x4 sA[8], sB[8];
+#define AO_LEAD_LOAD1(ST, CH, Q)                                                                     \
+  {                                                                                                  \
+    int64_t i_ = (CH) * kLeadKC + scol;                                                              \
+    if (i_ > last4) i_ = last4;                                                                      \
+    ST[Q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rowp[Q] + i_));                \
+  }
+#define AO_LEAD_LOAD(ST, CH) { _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) AO_LEAD_LOAD1(ST, CH, q_) }
+#define AO_LEAD_WRITE(ST, BUF)                                                                       \
+  {                                                                                                  \
+    float* base_ = lds + (BUF) * (kLeadRows * kLeadStride);                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                 \
+      *reinterpret_cast<f32x4*>(base_ + (srow + 16 * q_) * kLeadStride + scol) = ST[q_];             \
+  }
+  // consume chunk CH from LDS buffer BUF; if PF, refill register set ST with chunk CHN meanwhile
+#define AO_LEAD_COMPUTE(BUF, CH, ST, CHN, PF)                                                        \
+  {                                                                                                  \
+    const float* xs_ = lds + (BUF) * (kLeadRows * kLeadStride) + (32 * w + r32) * kLeadStride + 4 * h; \
+    f32x4 xv_[kLeadKC / 8], fv_[NT][kLeadKC / 8];                                                    \
+    _Pragma("unroll") for (int g = 0; g < kLeadKC / 8; ++g) {          /* all operands of the chunk up front */ \
+      int64_t gg = (CH) * (kLeadKC / 8) + g;                                                         \
+      if (gg >= a.Cg) gg = a.Cg - 1;                                   /* ragged last chunk: masked below */ \
+      xv_[g] = *reinterpret_cast<const f32x4*>(xs_ + 8 * g);                                         \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) fv_[nt][g] = fbase[nt * fnt + gg * 64];      \
+    }                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    _Pragma("unroll") for (int g = 0; g < kLeadKC / 8; ++g) {                                        \
+      if ((CH) * (kLeadKC / 8) + g < a.Cg) {                                                         \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                            \
+          _Pragma("unroll") for (int t = 0; t < 4; ++t)                                              \
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv_[g][t], fv_[nt][g][t], acc[nt], 0, 0, 0); \
+      }                                                                                              \
+      if (PF) AO_LEAD_LOAD1(ST, CHN, g)                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+    }                                                                                                \
+  }
+  const int64_t n = c1 > c0 ? c1 - c0 : 0;
+  if (n > 0) {
+    AO_LEAD_LOAD(sA, c0)
+    AO_LEAD_WRITE(sA, 0)
+  }
+  if (n > 1) AO_LEAD_LOAD(sA, c0 + 1)
+  if (n > 2) AO_LEAD_LOAD(sB, c0 + 2)
+  __syncthreads();
+  for (int64_t k = 0; k < n; k += 2) {
+    if (k + 1 < n) AO_LEAD_WRITE(sA, 1)
+    if (k + 3 < n) AO_LEAD_COMPUTE(0, c0 + k, sA, c0 + k + 3, true)
+    else AO_LEAD_COMPUTE(0, c0 + k, sA, c0, false)
+    __syncthreads();
+    if (k + 1 >= n) break;
+    if (k + 2 < n) AO_LEAD_WRITE(sB, 0)
+    if (k + 4 < n) AO_LEAD_COMPUTE(1, c0 + k + 1, sB, c0 + k + 4, true)
+    else AO_LEAD_COMPUTE(1, c0 + k + 1, sB, c0, false)
+    __syncthreads();
+  }
+#undef AO_LEAD_LOAD1
+#undef AO_LEAD_LOAD
+#undef AO_LEAD_WRITE
+#undef AO_LEAD_COMPUTE
+  double* Tc = a.T + (int64_t)slice * a.M * a.R;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r = 32 * nt + r32;
+    if (r < a.R) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rho = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int64_t m = m0 + 32 * w + rho;
+        if (m < a.M) Tc[m * a.R + r] = (double)acc[nt][i];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // f64 contraction (parity mode)
 // ---------------------------------------------------------------------------
 template <int NT>
@@ -315,9 +458,53 @@ ContractPlan make_plan(int64_t nbatch, int64_t batch_stride, int64_t M, int64_t 
   return p;
 }
 
+ContractPlan make_lead_plan(int64_t M, int64_t ld, int64_t C, int R) {
+  ContractPlan p;
+  p.nbatch = 1; p.batch_stride = 0; p.M = M; p.ld = ld; p.C = C; p.R = R;
+  p.lead = true;
+  const int64_t nch = cdiv(C, kLeadKC);
+  p.nchunk = (int)cdiv(nch, 2048 / kLeadKC);        // <= 2048 fp32-accumulated terms per slice
+  return p;
+}
+
+static void launch_contract_lead(const void* X, const ContractPlan& pl, const double* F, int64_t ldF, void* frag_ws,
+                                 double* T, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  const int64_t Cg = cdiv(pl.C, kGroup);
+  const int NT = nt_of(pl.R, AOADMM_PREC_F32);
+  AO_REQUIRE(pl.ld % 4 == 0 && pl.ld >= 4, "f32 layout must be padded to 4");
+  const int64_t total = (int64_t)NT * Cg * 256;
+  pack_frag_lead_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (float*)frag_ws);
+  AO_KERNEL_CHECK();
+  LArgs a;
+  a.X = (const float*)X; a.frag = (const float*)frag_ws; a.T = T;
+  a.M = pl.M; a.ld = pl.ld; a.C = pl.C; a.Cg = Cg; a.R = pl.R;
+  a.chunks_per_slice = (int)cdiv(cdiv(pl.C, kLeadKC), pl.nchunk);
+  const int64_t nblk = cdiv(pl.M, kLeadRows);
+  AO_REQUIRE(nblk < (int64_t)2147483647, "tensor too large for one launch");
+  dim3 grid((unsigned)nblk, (unsigned)pl.nchunk);
+  const size_t sh = (size_t)2 * kLeadRows * kLeadStride * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_lead_f32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_lead_f32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    attr = true;
+  }
+  if (ev0) AO_HIP(hipEventRecord(ev0, s));
+  if (NT == 1) contract_lead_f32<1><<<grid, 256, sh, s>>>(a);
+  else if (NT == 2) contract_lead_f32<2><<<grid, 256, sh, s>>>(a);
+  else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
+  if (ev1) AO_HIP(hipEventRecord(ev1, s));
+  AO_KERNEL_CHECK();
+}
+
 void launch_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
                      void* frag_ws, double* T, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   AO_REQUIRE(pl.R >= 1 && pl.R <= kMaxRank, "rank %d outside [1,%d]", pl.R, kMaxRank);
+  if (pl.lead) {
+    AO_REQUIRE(prec == AOADMM_PREC_F32, "leading-mode contraction exists for fp32 tensors only");
+    launch_contract_lead(X, pl, F, ldF, frag_ws, T, s, ev0, ev1);
+    return;
+  }
   const int64_t Cg = cdiv(pl.C, kGroup);
   const int NT = nt_of(pl.R, prec);
   KArgs a;

@@ -140,7 +140,7 @@ class Engine {
   // solve
   void solve(const aoadmm_options& opt, aoadmm_result* out);
   void resident_mttkrp(int p, int pos, double* out_host, float* ms);
-  void kernel_stats(int reset, double* ms, int64_t* launches, double* bytes, double* flops);
+  void kernel_stats(int which, int reset, double* ms, int64_t* launches, double* bytes, double* flops);
 
   // communicator
   void comm_init(const char id[128], int rank, int world);
@@ -189,7 +189,7 @@ class Engine {
   DevBuf redws_;         // reduction workspace
   DevBuf atbws_;
   DevBuf staging_;
-  KernelStats kstats_;
+  KernelStats kstats_[2];   // [0] streaming contraction, [1] leading-mode contraction
   bool profile_ = true;
   ncclComm_t comm_ = nullptr;
   int rank_ = 0, world_ = 1;

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 
@@ -36,7 +37,8 @@ Engine::Engine(int device) : device_(device) {
 
 Engine::~Engine() {
   (void)hipSetDevice(device_);
-  for (auto& pr : kstats_.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto& ks : kstats_)
+    for (auto& pr : ks.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (comm_) (void)ncclCommDestroy(comm_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -491,34 +493,37 @@ void Engine::state_get(int field, int index, int slab, double* host, int64_t row
 // ---------------------------------------------------------------------------
 void Engine::timed_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
                             void* frag, double* T) {
+  KernelStats& ks = kstats_[pl.lead ? 1 : 0];
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (profile_ && kstats_.pending.size() < 100000) {
+  if (profile_ && ks.pending.size() < 100000) {
     AO_HIP(hipEventCreate(&e0));
     AO_HIP(hipEventCreate(&e1));
   }
   launch_contract(X, prec, pl, F, ldF, frag, T, stream_, e0, e1);
-  if (e0) kstats_.pending.emplace_back(e0, e1);
-  kstats_.launches++;
-  kstats_.bytes += pl.algorithmic_bytes(prec);
-  kstats_.flops += pl.flops();
+  if (e0) ks.pending.emplace_back(e0, e1);
+  ks.launches++;
+  ks.bytes += pl.algorithmic_bytes(prec);
+  ks.flops += pl.flops();
 }
 
-void Engine::kernel_stats(int reset, double* ms, int64_t* launches, double* bytes, double* flops) {
+void Engine::kernel_stats(int which, int reset, double* ms, int64_t* launches, double* bytes, double* flops) {
+  AO_REQUIRE(which == 0 || which == 1, "kernel_stats: which must be 0 or 1");
   AO_HIP(hipSetDevice(device_));
   AO_HIP(hipStreamSynchronize(stream_));
-  for (auto& pr : kstats_.pending) {
+  KernelStats& ks = kstats_[which];
+  for (auto& pr : ks.pending) {
     float t = 0.f;
     AO_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
-    kstats_.ms += t;
+    ks.ms += t;
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
   }
-  kstats_.pending.clear();
-  if (ms) *ms = kstats_.ms;
-  if (launches) *launches = kstats_.launches;
-  if (bytes) *bytes = kstats_.bytes;
-  if (flops) *flops = kstats_.flops;
-  if (reset) { kstats_.ms = 0; kstats_.launches = 0; kstats_.bytes = 0; kstats_.flops = 0; }
+  ks.pending.clear();
+  if (ms) *ms = ks.ms;
+  if (launches) *launches = ks.launches;
+  if (bytes) *bytes = ks.bytes;
+  if (flops) *flops = ks.flops;
+  if (reset) { ks.ms = 0; ks.launches = 0; ks.bytes = 0; ks.flops = 0; }
 }
 
 // distance (in updates) until tensor position `c` is updated again after position `pos`
@@ -567,30 +572,44 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
     b.cached_mode = -1;
   } else if (b.nd == 3) {
     const int64_t J = b.dims[1], K = b.dims[2];
-    bool hit = use_cache && b.cached_mode >= 1 && b.cached_mode != pos &&
+    bool hit = use_cache && b.cached_mode >= 0 && b.cached_mode != pos &&
                facs[b.cached_mode].version == b.cached_version;
     if (!hit) {
-      int c;
-      if (pos == 1) c = 2;
-      else if (pos == 2) c = 1;
-      else c = (next_update_distance(pos, 1, update_seq, nseq) > next_update_distance(pos, 2, update_seq, nseq)) ? 1 : 2;
-      ContractPlan pl = (c == 2) ? make_plan(1, 0, Ip * J, Ip * J, K, R, prec)
-                                 : make_plan(K, Ip * J, Ip, Ip, J, R, prec);
+      // which mode to contract: any mode but `pos`; prefer the one whose factor stays unchanged longest so
+      // that the partial contraction also serves the next update (cycle 3->{1,2}, 2->{3,1}, 1->{2,3}:
+      // 1.5 tensor reads per outer iteration).  The leading mode needs the LDS-transposed kernel (fp32 only).
+      int c = -1, best = -1;
+      for (int cand = 2; cand >= 0; --cand) {
+        if (cand == pos) continue;
+        static const bool force_lead = getenv("AOADMM_FORCE_LEAD") != nullptr;   // development switch (tools/perf_mttkrp.py)
+        if (cand == 0 && !(prec == AOADMM_PREC_F32 && (use_cache || force_lead))) continue;
+        if (cand != 0 && force_lead && prec == AOADMM_PREC_F32 && pos != 0) continue;
+        const int dist = next_update_distance(pos, cand, update_seq, nseq);
+        if (dist > best) { best = dist; c = cand; }
+      }
+      ContractPlan pl;
+      const double* Fc = facs[c].p;
+      if (c == 2) pl = make_plan(1, 0, Ip * J, Ip * J, K, R, prec);
+      else if (c == 1) pl = make_plan(K, Ip * J, Ip, Ip, J, R, prec);
+      else { pl = make_lead_plan(J * K, Ip, I, R); Fc = F0; }
       b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
-      timed_contract(b.X.data.p, prec, pl, facs[c].p, facs[c].ld, b.frag.p, b.T.d());
+      timed_contract(b.X.data.p, prec, pl, Fc, facs[c].ld, b.frag.p, b.T.d());
       b.cached_mode = c; b.cached_version = facs[c].version; b.plan = pl;
     }
     const int c = b.cached_mode;
     const ContractPlan& pl = b.plan;
-    const int64_t Bn = (c == 2) ? J : K;           // second index of T's rows (i + Ip*b)
-    const int other = (c == 2) ? 1 : 2;            // tensor position of that index
-    if (pos == 0) {
-      b.scratch.ensure(reduce_outer_scratch_bytes(I, Bn, R));
-      launch_reduce_outer(b.T.d(), pl.nchunk, pl.trows(), I, Ip, Bn, R, facs[other].p, facs[other].ld, scale,
+    // T rows are (a + Apad*bb) with (a, bb) the two uncontracted modes in tensor order
+    const int ia = c == 0 ? 1 : 0, ib = c == 2 ? 1 : 2;
+    const int64_t An = ia == 0 ? I : J, Apad = ia == 0 ? Ip : J;
+    const int64_t Bn = ib == 1 ? J : K;
+    const double* Fa = ia == 0 ? F0 : facs[1].p;
+    if (pos == ia) {
+      b.scratch.ensure(reduce_outer_scratch_bytes(An, Bn, R));
+      launch_reduce_outer(b.T.d(), pl.nchunk, pl.trows(), An, Apad, Bn, R, facs[ib].p, facs[ib].ld, scale,
                           out_local, ldOut, b.scratch.d(), stream_);
     } else {
-      AO_REQUIRE(pos == other, "internal: cached contraction cannot serve this mode");
-      launch_reduce_inner(b.T.d(), pl.nchunk, pl.trows(), I, Ip, Bn, R, F0, facs[0].ld, scale, out_local, ldOut,
+      AO_REQUIRE(pos == ib, "internal: cached contraction cannot serve this mode");
+      launch_reduce_inner(b.T.d(), pl.nchunk, pl.trows(), An, Apad, Bn, R, Fa, facs[ia].ld, scale, out_local, ldOut,
                           stream_);
     }
   } else {
