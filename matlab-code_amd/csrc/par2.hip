@@ -353,6 +353,42 @@ __global__ __launch_bounds__(kP2Threads) void par2_bz_post_k(const double* B, co
     nk[4] = s0; nk[5] = s1; nk[6] = s2;
   }
 }
+// t_smoothness_prox.m:1-58 -- for every entry (j,r): tridiagonal system over the K slabs
+//   diag_k = 4*eta + rho_k (2*eta + rho_k at both ends), off-diagonals c = -2*eta, rhs_k = rho_k*V_k(j,r),
+// solved by the same Gaussian elimination (no pivoting, :42-46) and back substitution (:49-56) as the
+// reference.  The eliminated diagonal is the same for every entry; each thread keeps it in a local array.
+constexpr int kTsmoothMaxK = 64;
+__global__ void par2_tsmooth_k(const double* V, double* Z, const double* rho, double eta, P2Dims d, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  const int64_t n = d.off[1] * d.R;                    // entries per slab (all slabs equal)
+  const int K = d.K;
+  const double c = -2.0 * eta;
+  double dg[kTsmoothMaxK];
+  for (int k = 0; k < K; ++k) {
+    double a = 4.0 * eta + rho[k];                     // :25-34
+    if (k == 0) a -= 2.0 * eta;                        // :37
+    if (k == K - 1) a -= 2.0 * eta;                    // :38
+    if (k > 0) a -= (c / dg[k - 1]) * c;               // :43-44
+    dg[k] = a;
+  }
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    double rprev = rho[0] * V[e];                      // :8-10
+    Z[e] = rprev;                                      // eliminated rhs kept in Z until back substitution
+    for (int k = 1; k < K; ++k) {
+      const double m = c / dg[k - 1];                  // :43
+      const double rk = rho[k] * V[(int64_t)k * n + e] - m * rprev;   // :45
+      Z[(int64_t)k * n + e] = rk;
+      rprev = rk;
+    }
+    double q = rprev / dg[K - 1];                      // :50
+    Z[(int64_t)(K - 1) * n + e] = q;
+    for (int k = K - 2; k >= 0; --k) {                 // :53-56
+      q = (Z[(int64_t)k * n + e] - c * q) / dg[k];
+      Z[(int64_t)k * n + e] = q;
+    }
+  }
+}
+
 void par2_b_constraint(const ProxSpec& ps, const double* B, double* Z, double* muZ, double* Zold, double* V,
                        const double* rho, const P2Dims& d, double* prox_ws, double* norms, const AdmmCtl* ctl,
                        hipStream_t s) {
@@ -363,6 +399,12 @@ void par2_b_constraint(const ProxSpec& ps, const double* B, double* Z, double* m
   AO_KERNEL_CHECK();
   // Z_k = prox(B_k + muZ_k, rho_k) slab by slab (:568): every catalogue entry goes through prox_apply
   const int64_t* off = d.off_h;
+  if (ps.type == AOADMM_C_TPARAFAC2) {
+    AO_REQUIRE(d.K <= kTsmoothMaxK, "tPARAFAC2 on the device supports up to %d slabs", kTsmoothMaxK);
+    const int64_t ne = off[1] * d.R;
+    par2_tsmooth_k<<<(unsigned)cdiv(ne, 128), 128, 0, s>>>(V, Z, rho, ps.p0, d, ctl);
+    AO_KERNEL_CHECK();
+  } else
   for (int k = 0; k < d.K; ++k) {
     const int64_t Jk = off[k + 1] - off[k];
     prox_apply(ps, V + off[k] * d.R, Jk, Z + off[k] * d.R, Jk, Jk, d.R, rho + k, 1.0, prox_ws, ctl, s,
@@ -516,7 +558,9 @@ __global__ __launch_bounds__(kP2Threads) void par2_b_gaps_k(const double* B, con
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   const int64_t base = o * R;
-  double s0 = 0, s1 = 0, s2 = 0;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  const bool prev = k > 0 && (d.off[k] - d.off[k - 1]) == Jk;       // ||B_k - B_{k-1}||^2 (t_smoothness_penalty.m)
+  const int64_t pbase = prev ? d.off[k - 1] * R : 0;
   for (int e = threadIdx.x; e < Jk * R; e += blockDim.x) {
     const int j = e % Jk, r = e / Jk;
     double pd = 0.0;
@@ -525,9 +569,10 @@ __global__ __launch_bounds__(kP2Threads) void par2_b_gaps_k(const double* B, con
     s0 += (b - pd) * (b - pd);
     s1 += b * b;
     if (Z) s2 += (b - Z[base + e]) * (b - Z[base + e]);
+    if (prev) s3 += (b - B[pbase + e]) * (b - B[pbase + e]);
   }
-  s0 = block_sum_pow2(s0, red); s1 = block_sum_pow2(s1, red); s2 = block_sum_pow2(s2, red);
-  if (threadIdx.x == 0) { q[(int64_t)k * 4] = s0; q[(int64_t)k * 4 + 1] = s1; q[(int64_t)k * 4 + 2] = s2; q[(int64_t)k * 4 + 3] = 0; }
+  s0 = block_sum_pow2(s0, red); s1 = block_sum_pow2(s1, red); s2 = block_sum_pow2(s2, red); s3 = block_sum_pow2(s3, red);
+  if (threadIdx.x == 0) { q[(int64_t)k * 4] = s0; q[(int64_t)k * 4 + 1] = s1; q[(int64_t)k * 4 + 2] = s2; q[(int64_t)k * 4 + 3] = s3; }
 }
 void par2_b_gaps(const double* B, const double* P, const double* DeltaB, const double* Z, const P2Dims& d, double* q,
                  hipStream_t s) {

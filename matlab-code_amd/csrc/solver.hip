@@ -134,8 +134,9 @@ void Engine::set_constraint(int mode, int type, const double* params, int np, co
     case AOADMM_C_SIMPLEX_COL: case AOADMM_C_SIMPLEX_ROW: case AOADMM_C_UNIMODAL: case AOADMM_C_L1_BALL:
     case AOADMM_C_L2_BALL: case AOADMM_C_NONNEG_L2_BALL: case AOADMM_C_L1_REG: case AOADMM_C_L0_REG:
     case AOADMM_C_L2_REG: case AOADMM_C_RIDGE: case AOADMM_C_GL_SMOOTH: case AOADMM_C_TV: need(1); break;
-    case AOADMM_C_QUADRATIC: case AOADMM_C_TPARAFAC2:
-      throw Error(AOADMM_ERR_UNSUPPORTED, fmt("constraint id %d has no device prox yet (route to the MATLAB path)", type));
+    case AOADMM_C_TPARAFAC2: need(1); break;
+    case AOADMM_C_QUADRATIC:
+      throw Error(AOADMM_ERR_UNSUPPORTED, "'quadratic regularization' (dense user matrix) has no device prox yet (route to the MATLAB path)");
     default: break;
   }
   (void)Lmat;
@@ -177,7 +178,12 @@ void Engine::model_end() {
   for (int p = 0; p < n_tensors_; ++p) AO_REQUIRE(tensors_[p].defined, "tensor %d undefined", p);
   for (int m = 0; m < n_modes_; ++m) {
     const ModeInfo& mi = modes_[m];
+    if (mi.constrained && mi.prox.type == AOADMM_C_TPARAFAC2)       // cmtf_AOADMM.m:33-41
+      AO_REQUIRE(tensors_[mi.tensor].par2 && mi.pos == 1, "The tPARAFAC2 constraint can only be impsed on the second mode of a PARAFAC2 model");
     if (!tensors_[mi.tensor].par2) continue;
+    if (mi.pos == 1 && mi.constrained && mi.prox.type == AOADMM_C_TPARAFAC2)
+      for (int k = 1; k < mi.K; ++k)
+        AO_REQUIRE(mi.rows_k[k] == mi.rows_k[0], "tPARAFAC2 needs slabs of equal size (t_smoothness_prox.m adds B_k matrices)");
     if (mi.pos == 1) {
       // check_data_input.m:33-35
       AO_REQUIRE(mi.coupling < 0, "Coupling in 2. mode (the varying mode) of Parafac2 decomposition not supported.");
@@ -992,6 +998,11 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
           nb2 += q[4 * k + 1];
         }
         fpar += gp;
+        if (mB.constrained && mB.prox.type == AOADMM_C_TPARAFAC2) {        // t_smoothness_penalty.m via reg_func (:1276-1277)
+          double pen = 0.0;
+          for (int k = 1; k < b.K; ++k) pen += q[4 * k + 3];
+          ft += mB.prox.p0 * pen;
+        }
         if (mB.constrained) {
           const double g = gz / b.K;                                                            // :1339
           fcon += g;

@@ -135,3 +135,21 @@ def test_script1_cp_parafac2_coupled(pkg, eng, dims):
     rng = np.random.default_rng(12)
     Z, io = script1_model(rng, dims=dims)
     compare_par2(*run_both(pkg, eng, Z, io, options(MaxOuterIters=10)))
+
+
+def test_tparafac2_temporal_smoothness(pkg, eng):
+    """example_script11 family: regular PARAFAC2 with {'tPARAFAC2', eta} on the B_k mode
+    (t_smoothness_prox.m tridiagonal solve across slabs, t_smoothness_penalty.m in f_tensors)."""
+    from helpers import par2_slabs
+    rng = np.random.default_rng(13)
+    I, R, K, J = 25, 3, 9, 31
+    X, _ = par2_slabs(I, [J] * K, R, rng, noise=0.1)
+    Z = dict(loss_function=['Frobenius'], model=['PAR2'], modes=[[1, 2, 3]], size=[I, [J] * K, K],
+             coupling=dict(lin_coupled_modes=[0, 0, 0], coupling_type=[], coupl_trafo_matrices=[None] * 3),
+             constrained_modes=[0, 1, 1], constraints=[None, ('tPARAFAC2', 0.5), ('non-negativity',)],
+             weights=[1.0], object=[X])
+    distr = [lambda a, b: rng.standard_normal((a, b)), lambda a, b: rng.standard_normal((a, b)),
+             lambda a, b: rng.random((a, b)) + 0.1]
+    io = dict(lambdas_init=[[1] * R], nvecs=0, distr=distr, normalize=1)
+    opt = options(MaxOuterIters=10, iter_start_PAR2Bkconstraint=2, increase_factor_rhoBk=1.5)
+    compare_par2(*run_both(pkg, eng, Z, io, opt))
