@@ -21,10 +21,11 @@ void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, 
                 const AdmmCtl* ctl, hipStream_t s, const double* warm = nullptr, int64_t ldw = 0);
 // `warm`: optional previous value of the prox output (same shape); only a speed hint (TV warm start)
 
-// One iteration of ADMM_constrained_only (:608-620) for a CP mode.
-//   fusable prox : fac, Z, mu updated in one row-parallel kernel;
-//   other prox   : primal kernel -> column/matrix prox kernel -> dual kernel.
-// `part` holds >= admm_partials(rows) * 4 doubles; `V`,`Znew` are rows*R scratch (non-fusable only).
+// The whole ADMM_constrained_only loop (:596-622) for a CP mode, enqueued without host synchronisation:
+//   fusable prox : one row-parallel kernel per inner iteration (fac, Z, mu, residual partial sums);
+//   other prox   : primal kernel -> column/matrix prox kernel -> dual kernel per inner iteration.
+// The loop condition is evaluated on the device at the head of each iteration (admm.hip admm_continue).
+// `part` holds admm_partials(rows) * 4 doubles; `V`,`Znew` are rows*R scratch (non-fusable only).
 struct AdmmMode {
   const double* A;      // MTTKRP (+bsum term)            rows x R
   const double* L;      // chol factor                     R x R
@@ -36,9 +37,8 @@ struct AdmmMode {
   ProxSpec prox;
 };
 int admm_partials(int64_t rows);
-void admm_constrained_iteration(const AdmmMode& m, double* part, double* V, double* Znew, double* prox_ws,
-                                AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du,
-                                hipStream_t s);
+void admm_constrained_loop(const AdmmMode& m, double* part, double* V, double* Znew, double* prox_ws,
+                           AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du, hipStream_t s);
 
 // generic pieces for the coupled / PARAFAC2 loops -------------------------------
 // (Z,mu) <- update_constraint (:1420-1429): Zold kept in `Zold`; slots[0..3] receive

@@ -81,59 +81,260 @@ __device__ __forceinline__ void row_solve_regs2(double (&x)[RMAX], const double*
   }
 }
 
+// ---------------------------------------------------------------------------
+// Loop control without a kernel of its own.  The residuals of inner iteration k-1 are four sums that
+// iteration k-1 leaves as per-block partials in part[(k-1)&1]; the first thing every block of iteration
+// k's first kernel does is add them up (same data, same order => same decision in every block) and
+// evaluate eval_res_ADMM_constr (:1079-1096) + the while condition (:600).  Block 0 records the
+// outcome in ctl.  The later kernels of iteration k only look at ctl->active.
+// ---------------------------------------------------------------------------
+static constexpr int kMaxParts = 1024;     // partial-sum slots per parity
+static constexpr int kRowThreads = 64;
+
+__device__ __forceinline__ bool admm_continue(const double* part_prev, int nparts, int it, int max_inner,
+                                              double tol_pr, double tol_du, AdmmCtl* ctl, bool writer) {
+  const int active = ctl->active;
+  if (it == 0) return active != 0;
+  const int lane = threadIdx.x & 63;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int b = lane; b < nparts; b += 64) {
+    const double* pb = part_prev + (int64_t)b * 4;
+    s0 += pb[0]; s1 += pb[1]; s2 += pb[2]; s3 += pb[3];
+  }
+  for (int off = 32; off > 0; off >>= 1) {       // butterfly: every lane ends with the same total
+    s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off);
+    s2 += __shfl_xor(s2, off); s3 += __shfl_xor(s3, off);
+  }
+  const double pr = sqrt(s0) / sqrt(s1);                                   // :1085
+  const double sc = sqrt(s2);
+  const double du = sc > 0 ? sqrt(s3) / sc : sqrt(s3);                     // :1087-1092
+  const bool cont = it < max_inner && (pr > tol_pr || du > tol_du);        // :600
+  if (writer && active) {
+    ctl->res[1] = pr;
+    ctl->res[3] = du;
+    ctl->iters = it;
+    if (!cont) ctl->active = 0;
+  }
+  return active != 0 && cont;
+}
+
 struct FusedArgs {
   const double *A, *L, *rho, *Binv;
   double *fac, *Z, *mu, *V, *part;
+  AdmmCtl* ctl;
   int64_t rows;
   int R, fused, ptype;
-  double p0, p1;
+  int it, max_inner, nparts_prev;
+  double p0, p1, tol_pr, tol_du;
 };
 
-static constexpr int kRowThreads = 64;
+// branch-free form of the element-wise prox catalogue (same arithmetic per constraint as prox_elem):
+//   z = scale * clamp(hard(soft(v, g), thr0), lo, hi)
+struct ElemProx { double g, thr0, lo, hi, scale; };
+__device__ __forceinline__ ElemProx elem_prox_of(int type, double p0, double p1, double rho) {
+  ElemProx e{0.0, -1.0, -INFINITY, INFINITY, 1.0};
+  switch (type) {
+    case AOADMM_C_NONNEG: e.lo = 0.0; break;                              // project_box(x,0,inf)  (:14)
+    case AOADMM_C_BOX: e.lo = p0; e.hi = p1; break;                       // (:18)
+    case AOADMM_C_L1_REG: e.g = p0 / rho; break;                          // prox_abs(x,eta/rho) (:48)
+    case AOADMM_C_L0_REG: e.thr0 = 2.0 * (p0 / rho); break;               // prox_zero (:52)
+    case AOADMM_C_RIDGE: e.scale = 1.0 / (2.0 * (p0 / rho) + 1.0); break; // (:60)
+    default: break;
+  }
+  return e;
+}
+__device__ __forceinline__ double elem_prox(const ElemProx& e, double v) {
+  double s = v;
+  if (e.g != 0.0) { const double m = fabs(v) - e.g; s = m > 0.0 ? copysign(m, v) : 0.0; }
+  if (!(v * v > e.thr0)) s = 0.0;
+  return e.scale * fmin(fmax(s, e.lo), e.hi);
+}
 
-template <int RMAX>
-__global__ __launch_bounds__(kRowThreads) void admm_row_k(FusedArgs a, const AdmmCtl* ctl) {
-  CTL_GUARD(ctl);
-  extern __shared__ double Lsh[];
-  __shared__ double red[4][kRowThreads / 64];
-  const int R = a.R;
-  const bool use_inv = a.Binv != nullptr;
-  for (int e = threadIdx.x; e < R * R; e += blockDim.x) Lsh[e] = use_inv ? a.Binv[e] : a.L[e];
-  __syncthreads();
+// One inner iteration of ADMM_constrained_only for 64 rows per 256-thread block: wave w owns output
+// columns [w*CPW, (w+1)*CPW) of those rows (lane = row), so the per-row solve fac = A_inner*inv(L*L')
+// is spread over four waves and no thread carries more than R + 5*CPW operands in registers.
+// A_inner (:608) is exchanged through LDS, inv(L*L') is broadcast from LDS.  With an element-/row-wise
+// prox the kernel also does update_constraint (:1420-1429) and the residual partial sums; otherwise it
+// writes fac and V = fac + mu for the column prox kernel.
+// The kernel is latency-bound (2000 x 20 operands): every global load it needs -- operands, system
+// matrix, the previous iteration's partial sums -- is issued in ONE round trip before the loop decision.
+static constexpr int kRowBlock = 256;
+template <int CPW, bool EXACT>
+__global__ __launch_bounds__(kRowBlock) void admm_rows_k(FusedArgs a) {
+  constexpr int RMAX = 4 * CPW;
+  extern __shared__ double lds[];                   // Binv[R*R] | rhs[64][RP] | red[4][4]
+  const int R = EXACT ? RMAX : a.R;
+  const int RP = R | 1;
+  double* Bsh = lds;
+  double* rsh = lds + R * R;
+  double* red = rsh + 64 * RP;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t stride = (int64_t)gridDim.x * 64;
+  int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  bool have = i < a.rows;
+  // loads are unconditional on clamped (always valid) addresses: no exec-mask branches in the prologue,
+  // values of padding lanes / padding columns are never stored
+  double av[CPW], mu[CPW], zo[CPW];
+#pragma unroll
+  for (int k = 0; k < CPW; ++k) {
+    const int c = w * CPW + k;
+    const int64_t o = (have ? i : a.rows - 1) + a.rows * (c < R ? c : 0);
+    zo[k] = a.Z[o]; mu[k] = a.mu[o]; av[k] = a.A[o];
+  }
+  constexpr int NL = (RMAX * RMAX + kRowBlock - 1) / kRowBlock;
+  double lb[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int e = t + kRowBlock * k;
+    lb[k] = a.Binv[e < R * R ? e : 0];
+  }
   const double rho = a.rho[0];
+  const bool go = admm_continue(a.part + (int64_t)((a.it + 1) & 1) * kMaxParts * 4, a.nparts_prev, a.it, a.max_inner,
+                                a.tol_pr, a.tol_du, a.ctl, blockIdx.x == 0 && t == 0);
+  if (!go) return;                                  // block-uniform
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int e = t + kRowBlock * k;
+    if (e < R * R) Bsh[e] = lb[k];
+  }
   const double rh = rho / 2;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const ElemProx ep = elem_prox_of(a.ptype, a.p0, a.p1, rho);
   double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-  if (i < a.rows) {
+  for (;;) {
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+      const int c = w * CPW + k;
+      if (c < R) rsh[lane * RP + c] = av[k] + rh * (zo[k] - mu[k]);       // A_inner = A + rho/2*(Z - mu)   (:608)
+    }
+    __syncthreads();
+    double rhs[RMAX];
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) rhs[q] = q < R ? rsh[lane * RP + q] : 0.0;
+    double x[CPW];
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {                  // fac = A_inner * inv(L*L')       (:609)
+      const int c = w * CPW + k;
+      double acc = 0.0;
+      if (c < R) {
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q)
+          if (q < R) acc += rhs[q] * Bsh[q + R * c];
+      }
+      x[k] = acc;
+    }
+    if (a.fused) {
+      double z[CPW];
+#pragma unroll
+      for (int k = 0; k < CPW; ++k) z[k] = x[k] + mu[k];
+      if (a.ptype == AOADMM_C_SIMPLEX_ROW) {
+        // the projection needs the whole row: exchange fac + mu through LDS, every thread of a row finds
+        // the same threshold (exact nested-active-set iteration) and applies it to its own columns
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+          const int c = w * CPW + k;
+          if (c < R) rsh[lane * RP + c] = z[k];
+        }
+        __syncthreads();
+        double v[RMAX];
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q) v[q] = q < R ? rsh[lane * RP + q] : 0.0;
+        simplex_regs<RMAX>(v, R, a.p0);
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+          const int c = w * CPW + k;
+          z[k] = 0.0;
+#pragma unroll
+          for (int q = 0; q < RMAX; ++q)
+            if (q == c) z[k] = v[q];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) z[k] = elem_prox(ep, z[k]);
+      }
+      if (have) {
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+          const int c = w * CPW + k;
+          if (c < R) {
+            const int64_t o = i + a.rows * c;
+            const double mn = mu[k] + x[k] - z[k];     // mu = mu + fac - Z              (:1428)
+            a.fac[o] = x[k];
+            a.Z[o] = z[k];
+            a.mu[o] = mn;
+            const double d = x[k] - z[k];
+            s1 += d * d;
+            s2 += x[k] * x[k];
+            s3 += mn * mn;
+            const double e = z[k] - zo[k];
+            s4 += e * e;
+          }
+        }
+      }
+    } else if (have) {
+#pragma unroll
+      for (int k = 0; k < CPW; ++k) {
+        const int c = w * CPW + k;
+        if (c < R) {
+          const int64_t o = i + a.rows * c;
+          a.fac[o] = x[k];
+          a.V[o] = x[k] + mu[k];
+        }
+      }
+    }
+    i += stride;
+    if (i - lane >= a.rows) break;                    // block-uniform
+    have = i < a.rows;
+#pragma unroll
+    for (int k = 0; k < CPW; ++k) {
+      const int c = w * CPW + k;
+      const int64_t o = (have ? i : a.rows - 1) + a.rows * (c < R ? c : 0);
+      zo[k] = a.Z[o]; mu[k] = a.mu[o]; av[k] = a.A[o];
+    }
+    __syncthreads();                                  // rsh is rewritten at the top of the loop
+  }
+  if (a.fused) {
+    for (int off = 32; off > 0; off >>= 1) {        // fixed-order wave tree, then the four waves in order
+      s1 += __shfl_down(s1, off);
+      s2 += __shfl_down(s2, off);
+      s3 += __shfl_down(s3, off);
+      s4 += __shfl_down(s4, off);
+    }
+    if (lane == 0) { red[w * 4 + 0] = s1; red[w * 4 + 1] = s2; red[w * 4 + 2] = s3; red[w * 4 + 3] = s4; }
+    __syncthreads();
+    if (t < 4) {
+      a.part[((int64_t)(a.it & 1) * kMaxParts + blockIdx.x) * 4 + t] = red[t] + red[4 + t] + red[8 + t] + red[12 + t];
+    }
+  }
+}
+
+// Thread-per-row variant for the triangular-solve path (no explicit inverse available: op-level entry)
+template <int RMAX>
+__global__ __launch_bounds__(kRowThreads) void admm_rowL_k(FusedArgs a) {
+  extern __shared__ double Lsh[];
+  const int R = a.R;
+  for (int e = threadIdx.x; e < R * R; e += kRowThreads) Lsh[e] = a.L[e];
+  const double rho = a.rho[0];
+  const bool go = admm_continue(a.part + (int64_t)((a.it + 1) & 1) * kMaxParts * 4, a.nparts_prev, a.it, a.max_inner,
+                                a.tol_pr, a.tol_du, a.ctl, blockIdx.x == 0 && threadIdx.x == 0);
+  if (!go) return;
+  __syncthreads();
+  const double rh = rho / 2;
+  const ElemProx ep = elem_prox_of(a.ptype, a.p0, a.p1, rho);
+  double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kRowThreads + threadIdx.x; i < a.rows; i += (int64_t)gridDim.x * kRowThreads) {
     double x[RMAX], mu[RMAX], zo[RMAX];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
+      x[r] = 0; mu[r] = 0; zo[r] = 0;
       if (r < R) {
         const int64_t o = i + a.rows * r;
         zo[r] = a.Z[o];
         mu[r] = a.mu[o];
         x[r] = a.A[o] + rh * (zo[r] - mu[r]);       // A_inner = A + rho/2*(Z - mu)   (:608)
-      } else {
-        x[r] = 0; mu[r] = 0; zo[r] = 0;
       }
     }
-    if (use_inv) {                                  // fac = A_inner * inv(L*L')       (:609)
-      double rhs[RMAX];
-#pragma unroll
-      for (int r = 0; r < RMAX; ++r) rhs[r] = x[r];
-#pragma unroll
-      for (int r = 0; r < RMAX; ++r) {
-        if (r < R) {
-          double acc = 0.0;
-#pragma unroll
-          for (int q = 0; q < RMAX; ++q)
-            if (q < R) acc += rhs[q] * Lsh[q + R * r];
-          x[r] = acc;
-        }
-      }
-    } else {
-      row_solve_regs2<RMAX>(x, Lsh, R);             // fac = (A_inner/L')/L            (:609)
-    }
+    row_solve_regs2<RMAX>(x, Lsh, R);               // fac = (A_inner/L')/L            (:609)
     if (a.fused) {
       double z[RMAX];
 #pragma unroll
@@ -142,7 +343,7 @@ __global__ __launch_bounds__(kRowThreads) void admm_row_k(FusedArgs a, const Adm
         simplex_regs<RMAX>(z, R, a.p0);
       } else {
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) z[r] = prox_elem(a.ptype, z[r], a.p0, a.p1, rho);
+        for (int r = 0; r < RMAX; ++r) z[r] = elem_prox(ep, z[r]);
       }
 #pragma unroll
       for (int r = 0; r < RMAX; ++r) {
@@ -172,32 +373,35 @@ __global__ __launch_bounds__(kRowThreads) void admm_row_k(FusedArgs a, const Adm
     }
   }
   if (a.fused) {
-    // deterministic block reduction: wave shuffle tree then fixed-order sum over waves
     for (int off = 32; off > 0; off >>= 1) {
       s1 += __shfl_down(s1, off);
       s2 += __shfl_down(s2, off);
       s3 += __shfl_down(s3, off);
       s4 += __shfl_down(s4, off);
     }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][w] = s1; red[1][w] = s2; red[2][w] = s3; red[3][w] = s4; }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-      double t = 0;
-      for (int k = 0; k < kRowThreads / 64; ++k) t += red[threadIdx.x][k];
-      a.part[(int64_t)blockIdx.x * 4 + threadIdx.x] = t;
+    if (threadIdx.x == 0) {
+      double* pb = a.part + ((int64_t)(a.it & 1) * kMaxParts + blockIdx.x) * 4;
+      pb[0] = s1; pb[1] = s2; pb[2] = s3; pb[3] = s4;
     }
   }
 }
 
 int admm_partials(int64_t rows) {
-  const int64_t a = cdiv(rows, kRowThreads);
-  return (int)(a > 64 ? a : 64);
+  (void)rows;
+  return 2 * kMaxParts;                             // both parities
+}
+
+// records the residuals / iteration count of the last executed inner iteration when the loop ran to
+// MaxInnerIters (an earlier exit was recorded by the iteration that detected it)
+__global__ void admm_loop_end_k(const double* part, int nparts, int max_inner, double tol_pr, double tol_du,
+                                AdmmCtl* ctl) {
+  (void)admm_continue(part + (int64_t)((max_inner + 1) & 1) * kMaxParts * 4, nparts, max_inner, max_inner, tol_pr,
+                      tol_du, ctl, threadIdx.x == 0);
 }
 
 // element-wise dual update after a column-wise prox: mu += fac - Znew ; Z <- Znew ; partial norms
 __global__ void dual_update_k(const double* fac, double* Z, double* mu, const double* Znew, int64_t n,
-                              double* part, const AdmmCtl* ctl) {
+                              double* part, const AdmmCtl* ctl) {   // part: this iteration's parity block
   CTL_GUARD(ctl);
   __shared__ double red[4][4];
   double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
@@ -220,30 +424,6 @@ __global__ void dual_update_k(const double* fac, double* Z, double* mu, const do
     double t = 0;
     for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[threadIdx.x][k];
     part[(int64_t)blockIdx.x * 4 + threadIdx.x] = t;
-  }
-}
-
-// eval_res_ADMM_constr (:1079-1096) + loop condition (:600) for one mode
-__global__ void admm_finalize_k(const double* part, int nblocks, AdmmCtl* ctl, int max_inner, double tol_pr,
-                                double tol_du, double* slots) {
-  if (ctl->active == 0) return;
-  __shared__ double tot[4];
-  if (threadIdx.x < 4) {
-    double t = 0;
-    for (int b = 0; b < nblocks; ++b) t += part[(int64_t)b * 4 + threadIdx.x];
-    tot[threadIdx.x] = t;
-    if (slots) slots[threadIdx.x] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double pr = sqrt(tot[0]) / sqrt(tot[1]);
-    const double sc = sqrt(tot[2]);
-    const double du = sc > 0 ? sqrt(tot[3]) / sc : sqrt(tot[3]);
-    ctl->res[1] = pr;
-    ctl->res[3] = du;
-    const int it = ctl->iters + 1;
-    ctl->iters = it;
-    ctl->active = (it < max_inner && (pr > tol_pr || du > tol_du)) ? 1 : 0;
   }
 }
 
@@ -900,32 +1080,61 @@ void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, 
 // ===========================================================================
 // host-side composition
 // ===========================================================================
-void admm_constrained_iteration(const AdmmMode& m, double* part, double* V, double* Znew, double* prox_ws,
-                                AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du,
-                                hipStream_t s) {
+template <int CPW>
+static void launch_rows(const FusedArgs& a, unsigned blocks, hipStream_t s) {
+  const int RP = a.R | 1;
+  const size_t sh = ((size_t)a.R * a.R + (size_t)64 * RP + 16) * sizeof(double);
+  if (a.R == 4 * CPW) admm_rows_k<CPW, true><<<blocks, kRowBlock, sh, s>>>(a);
+  else admm_rows_k<CPW, false><<<blocks, kRowBlock, sh, s>>>(a);
+}
+static void launch_row_iteration(const FusedArgs& a, unsigned blocks, hipStream_t s) {
+  if (a.Binv) {
+    const int need = (a.R + 3) / 4;
+    if (need <= 1) launch_rows<1>(a, blocks, s);
+    else if (need <= 2) launch_rows<2>(a, blocks, s);
+    else if (need <= 3) launch_rows<3>(a, blocks, s);
+    else if (need <= 4) launch_rows<4>(a, blocks, s);
+    else if (need <= 5) launch_rows<5>(a, blocks, s);
+    else if (need <= 6) launch_rows<6>(a, blocks, s);
+    else if (need <= 8) launch_rows<8>(a, blocks, s);
+    else if (need <= 12) launch_rows<12>(a, blocks, s);
+    else launch_rows<16>(a, blocks, s);
+  } else {
+    const size_t sh = (size_t)a.R * a.R * sizeof(double);
+    if (a.R <= 8) admm_rowL_k<8><<<blocks, kRowThreads, sh, s>>>(a);
+    else if (a.R <= 16) admm_rowL_k<16><<<blocks, kRowThreads, sh, s>>>(a);
+    else if (a.R <= 32) admm_rowL_k<32><<<blocks, kRowThreads, sh, s>>>(a);
+    else admm_rowL_k<64><<<blocks, kRowThreads, sh, s>>>(a);
+  }
+}
+
+void admm_constrained_loop(const AdmmMode& m, double* part, double* V, double* Znew, double* prox_ws,
+                           AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du, hipStream_t s) {
   FusedArgs a;
   a.A = m.A; a.L = m.L; a.Binv = m.Binv; a.rho = m.rho; a.fac = m.fac; a.Z = m.Z; a.mu = m.mu; a.V = V; a.part = part;
+  a.ctl = ctl;
   a.rows = m.rows; a.R = m.R; a.ptype = m.prox.type; a.p0 = m.prox.p0; a.p1 = m.prox.p1;
   a.fused = prox_is_fusable(m.prox.type) ? 1 : 0;
-  const unsigned blocks = (unsigned)cdiv(m.rows, kRowThreads);
-  const size_t sh = (size_t)m.R * m.R * sizeof(double);
-  if (m.R <= 8) admm_row_k<8><<<blocks, kRowThreads, sh, s>>>(a, ctl);
-  else if (m.R <= 16) admm_row_k<16><<<blocks, kRowThreads, sh, s>>>(a, ctl);
-  else if (m.R <= 24) admm_row_k<24><<<blocks, kRowThreads, sh, s>>>(a, ctl);
-  else if (m.R <= 32) admm_row_k<32><<<blocks, kRowThreads, sh, s>>>(a, ctl);
-  else admm_row_k<64><<<blocks, kRowThreads, sh, s>>>(a, ctl);
-  AO_KERNEL_CHECK();
-  int nparts = (int)blocks;
-  if (!a.fused) {
-    prox_apply(m.prox, V, m.rows, Znew, m.rows, m.rows, m.R, m.rho, 1.0, prox_ws, ctl, s, m.Z, m.rows);
-    int64_t n = m.rows * m.R;
-    int64_t nb = cdiv(n, 1024);
-    if (nb > 64) nb = 64;
-    dual_update_k<<<(unsigned)nb, 256, 0, s>>>(m.fac, m.Z, m.mu, Znew, n, part, ctl);
+  a.max_inner = max_inner; a.tol_pr = tol_pr; a.tol_du = tol_du;
+  int64_t nblk = cdiv(m.rows, kRowThreads);
+  if (nblk > kMaxParts) nblk = kMaxParts;
+  const unsigned blocks = (unsigned)nblk;
+  const int64_t n = m.rows * m.R;
+  int64_t nbd = cdiv(n, 1024);
+  if (nbd > 64) nbd = 64;
+  const int nparts = a.fused ? (int)blocks : (int)nbd;
+  for (int it = 0; it < max_inner; ++it) {
+    a.it = it;
+    a.nparts_prev = nparts;
+    launch_row_iteration(a, blocks, s);
     AO_KERNEL_CHECK();
-    nparts = (int)nb;
+    if (!a.fused) {
+      prox_apply(m.prox, V, m.rows, Znew, m.rows, m.rows, m.R, m.rho, 1.0, prox_ws, ctl, s, m.Z, m.rows);
+      dual_update_k<<<(unsigned)nbd, 256, 0, s>>>(m.fac, m.Z, m.mu, Znew, n, part + (int64_t)(it & 1) * kMaxParts * 4, ctl);
+      AO_KERNEL_CHECK();
+    }
   }
-  admm_finalize_k<<<1, 64, 0, s>>>(part, nparts, ctl, max_inner, tol_pr, tol_du, nullptr);
+  admm_loop_end_k<<<1, 64, 0, s>>>(part, nparts, max_inner, tol_pr, tol_du, ctl);
   AO_KERNEL_CHECK();
 }
 

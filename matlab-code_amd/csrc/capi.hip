@@ -349,8 +349,7 @@ int aoadmm_op_admm_constrained(aoadmm_ctx* ctx, const double* A, const double* B
     AdmmMode am;
     am.A = a.d(); am.L = l.d(); am.rho = rh.d(); am.fac = f.d(); am.Z = z.d(); am.mu = m.d();
     am.rows = rows; am.R = R; am.prox = make_spec(constraint, params, n_params);
-    for (int it = 0; it < max_inner; ++it)
-      admm_constrained_iteration(am, part.d(), V.d(), Zn.d(), ws.d(), ctl.as<AdmmCtl>(), max_inner, tol_pr, tol_du, s);
+    admm_constrained_loop(am, part.d(), V.d(), Zn.d(), ws.d(), ctl.as<AdmmCtl>(), max_inner, tol_pr, tol_du, s);
     AdmmCtl h;
     AO_HIP(hipMemcpyAsync(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost, s));
     AO_HIP(hipStreamSynchronize(s));

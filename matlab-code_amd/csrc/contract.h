@@ -23,14 +23,17 @@ struct DenseTensor {
 
 // Description of one batched "contiguous-M" contraction
 //   T[b][m][r] = sum_{c<C} X[b*batch_stride + m + ld*c] * F[c][r]
-// (m contiguous in memory).  T is fp64, row-major [nchunk][nbatch*M][R].
+// (m contiguous in memory).  T is row-major [nchunk][nbatch*M][R] in the tensor's own precision: an
+// fp32 contraction accumulates in fp32 inside the MFMA, so storing its result as fp32 loses nothing and
+// halves the bytes the reductions read back; chunk sums are added in fp64 by the reductions.
 struct ContractPlan {
   int64_t nbatch, batch_stride, M, ld, C;
   int R;
+  int tprec = AOADMM_PREC_F64;   // element type of T
   int nchunk;          // split of the reduction (bounds f32 accumulation length)
   bool lead = false;   // true: the contracted mode is the contiguous one (X[c + ld*m]), LDS-transposed kernel
   int64_t trows() const { return nbatch * M; }
-  size_t t_bytes() const { return (size_t)nchunk * trows() * R * sizeof(double); }
+  size_t t_bytes() const { return (size_t)nchunk * trows() * R * (tprec == AOADMM_PREC_F32 ? 4 : 8); }
   size_t frag_bytes(int prec) const;
   double algorithmic_bytes(int prec) const {   // tensor read once + T written once
     return (double)nbatch * M * C * (prec == AOADMM_PREC_F32 ? 4.0 : 8.0) + (double)t_bytes();
@@ -46,21 +49,23 @@ ContractPlan make_lead_plan(int64_t M, int64_t ld, int64_t C, int R);
 
 // F: device fp64, column-major (C x R) with leading dimension ldF.
 void launch_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
-                     void* frag_ws, double* T, hipStream_t s, hipEvent_t ev0 = nullptr,
+                     void* frag_ws, void* T, hipStream_t s, hipEvent_t ev0 = nullptr,
                      hipEvent_t ev1 = nullptr);   // events bracket the contraction kernel only
 
 // out(b,r) = scale * sum_a sum_chunk T[chunk][a + Apad*b][r] * Fa(a,r)      (a < A)
-void launch_reduce_inner(const double* T, int nchunk, int64_t trows, int64_t A, int64_t Apad,
+// ft_scratch: reduce_factor_scratch_bytes(A, R) (row-major copy of the factor)
+size_t reduce_factor_scratch_bytes(int64_t rows, int R);
+void launch_reduce_inner(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
                          int64_t B, int R, const double* Fa, int64_t ldFa, double scale,
-                         double* out, int64_t ldOut, hipStream_t s);
+                         double* out, int64_t ldOut, double* ft_scratch, hipStream_t s);
 // out(a,r) = scale * sum_b sum_chunk T[chunk][a + Apad*b][r] * Fb(b,r)      (a < A)
-// scratch must hold reduce_outer_scratch_bytes().
+// scratch must hold reduce_outer_scratch_bytes(); ft_scratch reduce_factor_scratch_bytes(B, R).
 size_t reduce_outer_scratch_bytes(int64_t A, int64_t B, int R);
-void launch_reduce_outer(const double* T, int nchunk, int64_t trows, int64_t A, int64_t Apad,
+void launch_reduce_outer(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
                          int64_t B, int R, const double* Fb, int64_t ldFb, double scale,
-                         double* out, int64_t ldOut, double* scratch, hipStream_t s);
+                         double* out, int64_t ldOut, double* scratch, double* ft_scratch, hipStream_t s);
 // out(a,r) = scale * sum_chunk T[chunk][a][r]     (matrix blocks: nothing left to reduce)
-void launch_t_to_colmajor(const double* T, int nchunk, int64_t trows, int64_t A, int R, double scale,
+void launch_t_to_colmajor(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int R, double scale,
                           double* out, int64_t ldOut, hipStream_t s);
 
 }  // namespace aoadmm

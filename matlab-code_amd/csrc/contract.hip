@@ -19,6 +19,7 @@
 //      A[row l&15][k=l>>4]; a double2 load gives rows 2*(l&15)+v.
 #include "contract.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace aoadmm {
@@ -73,7 +74,7 @@ __global__ void pack_frag_f64(const double* __restrict__ F, int64_t ldF, int64_t
 struct KArgs {
   const void* X;
   const void* frag;
-  double* T;
+  void* T;             // float (f32 tensors) or double (f64 tensors), [nchunk][trows][R]
   int64_t tiles_per_batch, ntiles, batch_stride, M, ld, C, Cg, trows;
   int groups_per_chunk, R;
 };
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void contract_f32(KArgs a) {
 #undef AO_COMPUTE_STAGE
 #undef AO_MIX_STAGE
   // epilogue: C/D map col = lane&31, row rho = (reg&3) + 8*(reg>>2) + 4*(lane>>5); tile row = 4*rho+v
-  double* Tc = a.T + ((int64_t)chunk * a.trows + b * a.M) * a.R;
+  float* Tc = reinterpret_cast<float*>(a.T) + ((int64_t)chunk * a.trows + b * a.M) * a.R;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int r = 32 * nt + r4;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void contract_f32(KArgs a) {
         for (int i = 0; i < 16; ++i) {
           const int rho = (i & 3) + 8 * (i >> 2) + 4 * h;
           const int64_t m = m0 + 4 * rho + v;
-          if (m < a.M) Tc[m * a.R + r] = (double)acc[nt][v][i];
+          if (m < a.M) Tc[m * a.R + r] = acc[nt][v][i];
         }
     }
   }
@@ -231,7 +232,7 @@ __global__ void pack_frag_lead_f32(const double* __restrict__ F, int64_t ldF, in
 struct LArgs {
   const float* X;
   const float* frag;
-  double* T;
+  float* T;
   int64_t M, ld, C, Cg;      // rows of the unfolding, row stride, reduction length, groups of 8
   int chunks_per_slice;      // 64-element chunks per accumulation slice (blockIdx.y)
   int R;
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void contract_lead_f32(LArgs a) {
 #undef AO_LEAD_LOAD
 #undef AO_LEAD_WRITE
 #undef AO_LEAD_COMPUTE
-  double* Tc = a.T + (int64_t)slice * a.M * a.R;
+  float* Tc = a.T + (int64_t)slice * a.M * a.R;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int r = 32 * nt + r32;
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void contract_lead_f32(LArgs a) {
       for (int i = 0; i < 16; ++i) {
         const int rho = (i & 3) + 8 * (i >> 2) + 4 * h;
         const int64_t m = m0 + 32 * w + rho;
-        if (m < a.M) Tc[m * a.R + r] = (double)acc[nt][i];
+        if (m < a.M) Tc[m * a.R + r] = acc[nt][i];
       }
     }
   }
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) void contract_f64(KArgs a) {
   if (gfull < g1) stage(gfull, true);
 
   // C/D map (f64!): col = lane&15, row rho = (lane>>4) + 4*reg ; tile row = 32j + 2*rho + v
-  double* Tc = a.T + ((int64_t)chunk * a.trows + b * a.M) * a.R;
+  double* Tc = reinterpret_cast<double*>(a.T) + ((int64_t)chunk * a.trows + b * a.M) * a.R;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int r = 16 * nt + r2;
@@ -439,6 +440,7 @@ size_t ContractPlan::frag_bytes(int prec) const {
 ContractPlan make_plan(int64_t nbatch, int64_t batch_stride, int64_t M, int64_t ld, int64_t C, int R,
                        int prec) {
   ContractPlan p;
+  p.tprec = prec;
   p.nbatch = nbatch; p.batch_stride = batch_stride; p.M = M; p.ld = ld; p.C = C; p.R = R;
   const int64_t Cg = cdiv(C, kGroup);
   const int64_t ntiles = nbatch * cdiv(M, kTileRows);
@@ -460,6 +462,7 @@ ContractPlan make_plan(int64_t nbatch, int64_t batch_stride, int64_t M, int64_t 
 
 ContractPlan make_lead_plan(int64_t M, int64_t ld, int64_t C, int R) {
   ContractPlan p;
+  p.tprec = AOADMM_PREC_F32;
   p.nbatch = 1; p.batch_stride = 0; p.M = M; p.ld = ld; p.C = C; p.R = R;
   p.lead = true;
   const int64_t nch = cdiv(C, kLeadKC);
@@ -468,7 +471,7 @@ ContractPlan make_lead_plan(int64_t M, int64_t ld, int64_t C, int R) {
 }
 
 static void launch_contract_lead(const void* X, const ContractPlan& pl, const double* F, int64_t ldF, void* frag_ws,
-                                 double* T, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                                 void* T, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   const int64_t Cg = cdiv(pl.C, kGroup);
   const int NT = nt_of(pl.R, AOADMM_PREC_F32);
   AO_REQUIRE(pl.ld % 4 == 0 && pl.ld >= 4, "f32 layout must be padded to 4");
@@ -476,7 +479,7 @@ static void launch_contract_lead(const void* X, const ContractPlan& pl, const do
   pack_frag_lead_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (float*)frag_ws);
   AO_KERNEL_CHECK();
   LArgs a;
-  a.X = (const float*)X; a.frag = (const float*)frag_ws; a.T = T;
+  a.X = (const float*)X; a.frag = (const float*)frag_ws; a.T = (float*)T;
   a.M = pl.M; a.ld = pl.ld; a.C = pl.C; a.Cg = Cg; a.R = pl.R;
   a.chunks_per_slice = (int)cdiv(cdiv(pl.C, kLeadKC), pl.nchunk);
   const int64_t nblk = cdiv(pl.M, kLeadRows);
@@ -498,7 +501,8 @@ static void launch_contract_lead(const void* X, const ContractPlan& pl, const do
 }
 
 void launch_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
-                     void* frag_ws, double* T, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                     void* frag_ws, void* T, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  AO_REQUIRE(pl.tprec == prec, "contraction plan and tensor precision disagree");
   AO_REQUIRE(pl.R >= 1 && pl.R <= kMaxRank, "rank %d outside [1,%d]", pl.R, kMaxRank);
   if (pl.lead) {
     AO_REQUIRE(prec == AOADMM_PREC_F32, "leading-mode contraction exists for fp32 tensors only");
@@ -547,65 +551,141 @@ void launch_contract(const void* X, int prec, const ContractPlan& pl, const doub
 }
 
 // ---------------------------------------------------------------------------
-// reductions over T (fp64, deterministic summation order)
+// reductions over T (fp64 accumulation, deterministic summation order)
 // ---------------------------------------------------------------------------
-// one block per b; thread t -> (al = t / R, r = t % R); fixed-order LDS tree at the end
-__global__ void reduce_inner_k(const double* __restrict__ T, int nchunk, int64_t trows, int64_t A,
-                               int64_t Apad, int R, const double* __restrict__ Fa, int64_t ldFa,
-                               double scale, double* __restrict__ out, int64_t ldOut) {
-  extern __shared__ double sh[];
-  const int64_t b = blockIdx.x;
-  const int nA = blockDim.x / R;
-  const int t = threadIdx.x;
-  const int al = t / R, r = t - al * R;
-  double sum = 0.0;
-  if (al < nA) {
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const double* Tb = T + ((int64_t)ch * trows + Apad * b) * R;
-      for (int64_t a = al; a < A; a += nA) sum += Tb[a * R + r] * Fa[a + ldFa * r];
-    }
-    sh[t] = sum;
+// T is read with the factor in the SAME row-major [row][r] order (the factor is transposed into a small
+// scratch first): both operands of every product come from one flat, fully coalesced index, instead of
+// 20-64 scattered cache lines per wave load of the column-major factor.  Each thread keeps four
+// independent accumulators, i.e. four loads of each stream in flight.
+__global__ void factor_rowmajor_k(const double* __restrict__ F, int64_t ldF, int64_t rows, int R,
+                                  double* __restrict__ Ft) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // over rows * R, row fastest
+  if (idx >= rows * R) return;
+  const int r = (int)(idx / rows);
+  const int64_t a = idx - (int64_t)r * rows;
+  Ft[a * R + r] = F[a + ldF * r];
+}
+static void factor_rowmajor(const double* F, int64_t ldF, int64_t rows, int R, double* Ft, hipStream_t s) {
+  factor_rowmajor_k<<<(unsigned)cdiv(rows * R, 256), 256, 0, s>>>(F, ldF, rows, R, Ft);
+  AO_KERNEL_CHECK();
+}
+
+// VEC consecutive r per thread (16-byte loads of T when the rank allows it: VEC = 4 for fp32, 2 for fp64)
+template <typename TT, int VEC> struct TVec;
+template <> struct TVec<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct TVec<float, 1> { typedef float type; };
+template <> struct TVec<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct TVec<double, 1> { typedef double type; };
+template <typename TT, int VEC>
+__device__ __forceinline__ void fma_vec(double (&acc)[VEC], const TT* __restrict__ tp, const double* __restrict__ fp) {
+  typedef typename TVec<TT, VEC>::type V;
+  const V tv = *reinterpret_cast<const V*>(tp);
+  if constexpr (VEC == 1) {
+    acc[0] += (double)tv * fp[0];
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] += (double)tv[v] * fp[v];
   }
+}
+
+// one block per b; the A x R slab of T and the row-major factor are walked with the same flat index.
+// blockDim * VEC is a multiple of R, so a thread's r's are fixed while its a advances.
+template <typename TT, int VEC>
+__global__ void reduce_inner_k(const TT* __restrict__ T, int nchunk, int64_t trows, int64_t A, int64_t Apad, int R,
+                               const double* __restrict__ FaT, double scale, double* __restrict__ out,
+                               int64_t ldOut) {
+  extern __shared__ double sh[];                      // blockDim * VEC
+  const int64_t b = blockIdx.x;
+  const int t = threadIdx.x;
+  const int64_t n = A * R, step = (int64_t)blockDim.x * VEC;
+  double s0[VEC], s1[VEC], s2[VEC], s3[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { s0[v] = 0; s1[v] = 0; s2[v] = 0; s3[v] = 0; }
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const TT* Tb = T + ((int64_t)ch * trows + Apad * b) * R;
+    int64_t e = (int64_t)t * VEC;
+    for (; e + 3 * step < n; e += 4 * step) {
+      fma_vec<TT, VEC>(s0, Tb + e, FaT + e);
+      fma_vec<TT, VEC>(s1, Tb + e + step, FaT + e + step);
+      fma_vec<TT, VEC>(s2, Tb + e + 2 * step, FaT + e + 2 * step);
+      fma_vec<TT, VEC>(s3, Tb + e + 3 * step, FaT + e + 3 * step);
+    }
+    for (; e < n; e += step) fma_vec<TT, VEC>(s0, Tb + e, FaT + e);
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) sh[t * VEC + v] = (s0[v] + s1[v]) + (s2[v] + s3[v]);
   __syncthreads();
-  if (t < R) {
+  if (t < R) {                                        // flat slot q holds r = q % R
+    const int nA = blockDim.x * VEC / R;
     double tot = 0.0;
     for (int i = 0; i < nA; ++i) tot += sh[i * R + t];
     out[b + ldOut * t] = scale * tot;
   }
 }
 
-void launch_reduce_inner(const double* T, int nchunk, int64_t trows, int64_t A, int64_t Apad,
+size_t reduce_factor_scratch_bytes(int64_t rows, int R) { return (size_t)rows * R * sizeof(double); }
+
+template <typename TT, int VEC>
+static void launch_inner_t(const void* T, int nchunk, int64_t trows, int64_t A, int64_t Apad, int64_t B, int R,
+                           const double* FaT, double scale, double* out, int64_t ldOut, hipStream_t s) {
+  const int rq = R / VEC;                             // threads per row of T
+  int threads = 256 / rq * rq;
+  if (threads < rq) threads = rq;
+  if (threads * VEC < R) threads = (R + VEC - 1) / VEC;
+  reduce_inner_k<TT, VEC><<<(unsigned)B, threads, (size_t)threads * VEC * sizeof(double), s>>>(
+      (const TT*)T, nchunk, trows, A, Apad, R, FaT, scale, out, ldOut);
+}
+
+void launch_reduce_inner(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
                          int64_t B, int R, const double* Fa, int64_t ldFa, double scale,
-                         double* out, int64_t ldOut, hipStream_t s) {
-  int threads = 256 / R * R;
-  if (threads < R) threads = R;
-  reduce_inner_k<<<(unsigned)B, threads, threads * sizeof(double), s>>>(T, nchunk, trows, A, Apad, R, Fa, ldFa,
-                                                                       scale, out, ldOut);
+                         double* out, int64_t ldOut, double* ft_scratch, hipStream_t s) {
+  factor_rowmajor(Fa, ldFa, A, R, ft_scratch, s);
+  // 16-byte loads need every slab (Apad*R elements) and every chunk (trows*R) to start 16-byte aligned
+  if (tprec == AOADMM_PREC_F32) {
+    if (R % 4 == 0) launch_inner_t<float, 4>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s);
+    else launch_inner_t<float, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s);
+  } else {
+    if (R % 2 == 0) launch_inner_t<double, 2>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s);
+    else launch_inner_t<double, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s);
+  }
   AO_KERNEL_CHECK();
 }
 
-static void outer_geometry(int64_t A, int64_t B, int R, int& TA, int64_t& nblkA, int& SB) {
-  TA = 256 / R;
+// out(a, r) = sum_b T[a + Apad*b][r] * Fb(b, r): block = TA consecutive rows a x (R/VEC) r-groups, grid.y
+// slices of b; partial sums per slice are added in slice order by reduce_outer_fin.
+static void outer_geometry(int64_t A, int64_t B, int R, int vec, int& TA, int64_t& nblkA, int& SB) {
+  const int rq = (R + vec - 1) / vec;
+  TA = 256 / rq;
   if (TA < 1) TA = 1;
   nblkA = cdiv(A, TA);
-  int64_t sb = cdiv(1024, nblkA);
+  int64_t sb = cdiv(2048, nblkA);
   if (sb > 64) sb = 64;
   if (sb > B) sb = B;
   if (sb < 1) sb = 1;
   SB = (int)sb;
 }
-
-size_t reduce_outer_scratch_bytes(int64_t A, int64_t B, int R) {
-  int TA, SB; int64_t nb;
-  outer_geometry(A, B, R, TA, nb, SB);
-  return (size_t)SB * A * R * sizeof(double);
+static int outer_vec(int tprec, int R) {
+  if (tprec == AOADMM_PREC_F32) return R % 4 == 0 ? 4 : 1;
+  return R % 2 == 0 ? 2 : 1;
 }
 
-__global__ void reduce_outer_k(const double* __restrict__ T, int nchunk, int64_t trows, int64_t A,
-                               int64_t Apad, int64_t B, int R, int TA, const double* __restrict__ Fb,
-                               int64_t ldFb, double* __restrict__ part) {
+size_t reduce_outer_scratch_bytes(int64_t A, int64_t B, int R) {
+  size_t worst = 0;
+  for (int vec : {1, 2, 4}) {
+    int TA, SB; int64_t nb;
+    outer_geometry(A, B, R, vec, TA, nb, SB);
+    worst = std::max(worst, (size_t)SB * A * R * sizeof(double));
+  }
+  return worst;
+}
+
+template <typename TT, int VEC>
+__global__ void reduce_outer_k(const TT* __restrict__ T, int nchunk, int64_t trows, int64_t A,
+                               int64_t Apad, int64_t B, int R, int TA, const double* __restrict__ FbT,
+                               double* __restrict__ part) {
   const int t = threadIdx.x;
-  const int al = t / R, r = t - al * R;
+  const int rq = R / VEC;
+  const int al = t / rq, r = (t - al * rq) * VEC;
   const int64_t a = (int64_t)blockIdx.x * TA + al;
   const int SB = gridDim.y, sb = blockIdx.y;
   const int64_t bper = (B + SB - 1) / SB;
@@ -613,13 +693,24 @@ __global__ void reduce_outer_k(const double* __restrict__ T, int nchunk, int64_t
   int64_t b1 = b0 + bper;
   if (b1 > B) b1 = B;
   if (al >= TA || a >= A) return;
-  double sum = 0.0;
+  const int64_t bs = Apad * R;                       // T stride between consecutive b
+  double s0[VEC], s1[VEC], s2[VEC], s3[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { s0[v] = 0; s1[v] = 0; s2[v] = 0; s3[v] = 0; }
   for (int ch = 0; ch < nchunk; ++ch) {
-    const double* Tc = T + (int64_t)ch * trows * R + a * R + r;
-#pragma unroll 4
-    for (int64_t b = b0; b < b1; ++b) sum += Tc[Apad * b * R] * Fb[b + ldFb * r];
+    const TT* Tc = T + (int64_t)ch * trows * R + a * R + r;
+    const double* Fr = FbT + r;
+    int64_t b = b0;
+    for (; b + 3 < b1; b += 4) {
+      fma_vec<TT, VEC>(s0, Tc + bs * b, Fr + b * R);
+      fma_vec<TT, VEC>(s1, Tc + bs * (b + 1), Fr + (b + 1) * R);
+      fma_vec<TT, VEC>(s2, Tc + bs * (b + 2), Fr + (b + 2) * R);
+      fma_vec<TT, VEC>(s3, Tc + bs * (b + 3), Fr + (b + 3) * R);
+    }
+    for (; b < b1; ++b) fma_vec<TT, VEC>(s0, Tc + bs * b, Fr + b * R);
   }
-  part[((int64_t)sb * A + a) * R + r] = sum;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) part[((int64_t)sb * A + a) * R + r + v] = (s0[v] + s1[v]) + (s2[v] + s3[v]);
 }
 
 __global__ void reduce_outer_fin(const double* __restrict__ part, int SB, int64_t A, int R, double scale,
@@ -628,39 +719,62 @@ __global__ void reduce_outer_fin(const double* __restrict__ part, int SB, int64_
   if (idx >= A * R) return;
   const int64_t a = idx / R;
   const int r = (int)(idx - a * R);
-  double tot = 0.0;
-  for (int s = 0; s < SB; ++s) tot += part[(int64_t)s * A * R + idx];
-  out[a + ldOut * r] = scale * tot;
+  double t0 = 0.0, t1 = 0.0;
+  int s = 0;
+  for (; s + 1 < SB; s += 2) {
+    t0 += part[(int64_t)s * A * R + idx];
+    t1 += part[(int64_t)(s + 1) * A * R + idx];
+  }
+  if (s < SB) t0 += part[(int64_t)s * A * R + idx];
+  out[a + ldOut * r] = scale * (t0 + t1);
 }
 
-void launch_reduce_outer(const double* T, int nchunk, int64_t trows, int64_t A, int64_t Apad,
-                         int64_t B, int R, const double* Fb, int64_t ldFb, double scale,
-                         double* out, int64_t ldOut, double* scratch, hipStream_t s) {
-  int TA, SB; int64_t nb;
-  outer_geometry(A, B, R, TA, nb, SB);
-  int threads = TA * R;
+template <typename TT, int VEC>
+static void launch_outer_t(const void* T, int nchunk, int64_t trows, int64_t A, int64_t Apad, int64_t B, int R,
+                           const double* FbT, double* scratch, int& SB, hipStream_t s) {
+  int TA; int64_t nb;
+  outer_geometry(A, B, R, VEC, TA, nb, SB);
+  int threads = TA * (R / VEC);
   threads = (threads + 63) / 64 * 64;
-  reduce_outer_k<<<dim3((unsigned)nb, (unsigned)SB), threads, 0, s>>>(T, nchunk, trows, A, Apad, B, R, TA, Fb, ldFb,
-                                                                     scratch);
+  reduce_outer_k<TT, VEC><<<dim3((unsigned)nb, (unsigned)SB), threads, 0, s>>>((const TT*)T, nchunk, trows, A, Apad, B,
+                                                                             R, TA, FbT, scratch);
+}
+
+void launch_reduce_outer(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
+                         int64_t B, int R, const double* Fb, int64_t ldFb, double scale,
+                         double* out, int64_t ldOut, double* scratch, double* ft_scratch, hipStream_t s) {
+  factor_rowmajor(Fb, ldFb, B, R, ft_scratch, s);
+  int SB = 1;
+  const int vec = outer_vec(tprec, R);
+  if (tprec == AOADMM_PREC_F32) {
+    if (vec == 4) launch_outer_t<float, 4>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s);
+    else launch_outer_t<float, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s);
+  } else {
+    if (vec == 2) launch_outer_t<double, 2>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s);
+    else launch_outer_t<double, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s);
+  }
   AO_KERNEL_CHECK();
   reduce_outer_fin<<<(unsigned)cdiv(A * R, 256), 256, 0, s>>>(scratch, SB, A, R, scale, out, ldOut);
   AO_KERNEL_CHECK();
 }
 
-__global__ void t_to_colmajor_k(const double* __restrict__ T, int nchunk, int64_t trows, int64_t A, int R,
+template <typename TT>
+__global__ void t_to_colmajor_k(const TT* __restrict__ T, int nchunk, int64_t trows, int64_t A, int R,
                                 double scale, double* __restrict__ out, int64_t ldOut) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= A * R) return;
   const int64_t a = idx / R;
   const int r = (int)(idx - a * R);
   double tot = 0.0;
-  for (int ch = 0; ch < nchunk; ++ch) tot += T[(int64_t)ch * trows * R + idx];
+  for (int ch = 0; ch < nchunk; ++ch) tot += (double)T[(int64_t)ch * trows * R + idx];
   out[a + ldOut * r] = scale * tot;
 }
 
-void launch_t_to_colmajor(const double* T, int nchunk, int64_t trows, int64_t A, int R, double scale,
+void launch_t_to_colmajor(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int R, double scale,
                           double* out, int64_t ldOut, hipStream_t s) {
-  t_to_colmajor_k<<<(unsigned)cdiv(A * R, 256), 256, 0, s>>>(T, nchunk, trows, A, R, scale, out, ldOut);
+  const unsigned nb = (unsigned)cdiv(A * R, 256);
+  if (tprec == AOADMM_PREC_F32) t_to_colmajor_k<float><<<nb, 256, 0, s>>>((const float*)T, nchunk, trows, A, R, scale, out, ldOut);
+  else t_to_colmajor_k<double><<<nb, 256, 0, s>>>((const double*)T, nchunk, trows, A, R, scale, out, ldOut);
   AO_KERNEL_CHECK();
 }
 

@@ -45,6 +45,27 @@ void sumsq_diff(double* slot, const double* x, const double* y, int64_t n, doubl
 // slot[0] = sum x.*y
 void dot(double* slot, const double* x, const double* y, int64_t n, double* ws, const AdmmCtl* ctl,
          hipStream_t s);
+// Several independent reductions in one launch.  RT_SUMSQ_DIFF: sum (x-y)^2 (y may be null) over n;
+// RT_DOT: sum x.*y over n; RT_REG: value of the regulariser `aux` (AOADMM_C_* id: l1, l0, ridge, TV,
+// GL smoothness; constraints_to_prox.m reg_func) of the rows x R matrix x.  slot[0] = scale * sum.
+enum { RT_SUMSQ_DIFF = 0, RT_DOT = 1, RT_REG = 2 };
+struct ReduceTask {
+  const double* x = nullptr;
+  const double* y = nullptr;
+  int64_t n = 0, rows = 0;
+  double* slot = nullptr;
+  double scale = 1.0;
+  int kind = RT_SUMSQ_DIFF, R = 0, aux = 0;
+};
+constexpr int kReduceBatchMax = 40;
+constexpr int kReduceBatchSplit = 64;
+struct ReduceBatch {
+  ReduceTask t[kReduceBatchMax];
+  int n = 0;
+  void add(const ReduceTask& k) { if (n < kReduceBatchMax) t[n] = k; ++n; }   // overflow is caught by reduce_batch
+};
+// ws >= kReduceBatchMax * kReduceBatchSplit doubles
+void reduce_batch(const ReduceBatch& rb, double* ws, hipStream_t s);
 // X <- RHS * inv(L*L')   (L lower R x R; per-row forward/backward substitution, cmtf_fun_AOADMM.m:609)
 void row_solve(double* X, int64_t ldx, const double* RHS, int64_t ldr, const double* L, int64_t I, int R,
                const AdmmCtl* ctl, hipStream_t s);

@@ -2,6 +2,8 @@
 #include "small.h"
 #include "device_utils.h"
 
+#include <algorithm>
+
 namespace aoadmm {
 
 #define CTL_GUARD(ctl) \
@@ -133,13 +135,23 @@ __global__ void atb_part_k(const double* A, int64_t lda, const double* B, int64_
     if (e < KN) ws[(int64_t)blockIdx.x * KN + e] = acc[q];
   }
 }
-__global__ void atb_fin_k(double* out, const double* ws, int nb, int KN, const AdmmCtl* ctl) {
+// 32 entries x 8 slices per block: slice sl adds partials sl, sl+8, ... (independent loads, one memory
+// round trip), then the 8 slice sums are added in a fixed order
+__global__ __launch_bounds__(256) void atb_fin_k(double* out, const double* ws, int nb, int KN, const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
-  for (int e = threadIdx.x; e < KN; e += blockDim.x) {
-    double t = 0.0;
-#pragma unroll 8
-    for (int b = 0; b < nb; ++b) t += ws[(int64_t)b * KN + e];     // fixed order; loads issue ahead of the adds
-    out[e] = t;
+  __shared__ double sh[8][32];
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
+  double t = 0.0;
+  if (e < KN)
+    for (int b = sl; b < nb; b += 8) t += ws[(int64_t)b * KN + e];
+  sh[sl][el] = t;
+  __syncthreads();
+  if (sl == 0 && e < KN) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tot += sh[q][el];
+    out[e] = tot;
   }
 }
 void atb_small(double* out, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t I,
@@ -148,8 +160,103 @@ void atb_small(double* out, const double* A, int64_t lda, const double* B, int64
   const size_t sh = (size_t)kAtbRows * (K + N + 2) * sizeof(double);
   atb_part_k<<<nb, 256, sh, s>>>(A, lda, B, ldb, I, K, N, ws, ctl);
   AO_KERNEL_CHECK();
-  atb_fin_k<<<1, 256, 0, s>>>(out, ws, nb, K * N, ctl);
+  atb_fin_k<<<(unsigned)cdiv(K * N, 32), 256, 0, s>>>(out, ws, nb, K * N, ctl);
   AO_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// batch of independent reductions in one launch (the objective evaluation needs ~10 of them per outer
+// iteration; one kernel each was ~10 us of latency apiece).  grid = (nsplit, ntasks); fixed summation order.
+__device__ __forceinline__ double block256_sum(double v, double* sh4) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double r = sh4[0] + sh4[1] + sh4[2] + sh4[3];
+  __syncthreads();
+  return r;
+}
+__global__ __launch_bounds__(256) void reduce_batch_k(ReduceBatch rb, double* ws) {
+  __shared__ double sh4[4];
+  const ReduceTask& tk = rb.t[blockIdx.y];
+  const int nsplit = gridDim.x, sp = blockIdx.x;
+  double acc = 0.0;
+  if (tk.kind == RT_SUMSQ_DIFF || tk.kind == RT_DOT) {
+    const int64_t per = (tk.n + nsplit - 1) / nsplit;
+    const int64_t e0 = sp * per;
+    int64_t e1 = e0 + per;
+    if (e1 > tk.n) e1 = tk.n;
+    // four independent accumulators per thread: four (eight) loads in flight instead of one
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int64_t e = e0 + threadIdx.x;
+    if (tk.kind == RT_DOT) {
+      for (; e + 768 < e1; e += 1024) {
+        a0 += tk.x[e] * tk.y[e]; a1 += tk.x[e + 256] * tk.y[e + 256];
+        a2 += tk.x[e + 512] * tk.y[e + 512]; a3 += tk.x[e + 768] * tk.y[e + 768];
+      }
+      for (; e < e1; e += 256) a0 += tk.x[e] * tk.y[e];
+    } else if (tk.y) {
+      for (; e + 768 < e1; e += 1024) {
+        const double d0 = tk.x[e] - tk.y[e], d1 = tk.x[e + 256] - tk.y[e + 256];
+        const double d2 = tk.x[e + 512] - tk.y[e + 512], d3 = tk.x[e + 768] - tk.y[e + 768];
+        a0 += d0 * d0; a1 += d1 * d1; a2 += d2 * d2; a3 += d3 * d3;
+      }
+      for (; e < e1; e += 256) { const double d = tk.x[e] - tk.y[e]; a0 += d * d; }
+    } else {
+      for (; e + 768 < e1; e += 1024) {
+        const double d0 = tk.x[e], d1 = tk.x[e + 256], d2 = tk.x[e + 512], d3 = tk.x[e + 768];
+        a0 += d0 * d0; a1 += d1 * d1; a2 += d2 * d2; a3 += d3 * d3;
+      }
+      for (; e < e1; e += 256) { const double d = tk.x[e]; a0 += d * d; }
+    }
+    acc = (a0 + a1) + (a2 + a3);
+  } else {
+    // regulariser values of constraints_to_prox.m (:50,:54,:58 and the difference forms :75,:81), column by column
+    const int64_t per = (tk.rows + nsplit - 1) / nsplit;
+    const int64_t i0 = sp * per;
+    int64_t i1 = i0 + per;
+    if (i1 > tk.rows) i1 = tk.rows;
+#pragma unroll 4
+    for (int r = 0; r < tk.R; ++r) {
+      const double* x = tk.x + tk.rows * r;
+      for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const double v = x[i];
+        switch (tk.aux) {
+          case AOADMM_C_L1_REG: acc += fabs(v); break;
+          case AOADMM_C_L0_REG: acc += (v != 0.0) ? 1.0 : 0.0; break;
+          case AOADMM_C_RIDGE: acc += v * v; break;
+          case AOADMM_C_TV: if (i + 1 < tk.rows) acc += x[i + 1] - v; break;          // no abs(): quirk of :81
+          case AOADMM_C_GL_SMOOTH: if (i + 1 < tk.rows) { const double d = x[i + 1] - v; acc += d * d; } break;
+          default: break;
+        }
+      }
+    }
+  }
+  const double tot = block256_sum(acc, sh4);
+  if (threadIdx.x == 0) {
+    if (nsplit == 1) tk.slot[0] = tk.scale * tot;
+    else ws[(int64_t)blockIdx.y * nsplit + sp] = tot;
+  }
+}
+__global__ void reduce_batch_fin_k(ReduceBatch rb, const double* ws, int nsplit) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= rb.n) return;
+  double t = 0.0;
+  for (int q = 0; q < nsplit; ++q) t += ws[(int64_t)k * nsplit + q];
+  rb.t[k].slot[0] = rb.t[k].scale * t;
+}
+void reduce_batch(const ReduceBatch& rb, double* ws, hipStream_t s) {
+  if (rb.n <= 0) return;
+  AO_REQUIRE(rb.n <= kReduceBatchMax, "reduce_batch: too many tasks");
+  int64_t big = 0;
+  for (int k = 0; k < rb.n; ++k) big = std::max<int64_t>(big, rb.t[k].kind >= RT_REG ? rb.t[k].rows * rb.t[k].R : rb.t[k].n);
+  int nsplit = (int)std::min<int64_t>(kReduceBatchSplit, cdiv(big, 8192));
+  if (nsplit < 1) nsplit = 1;
+  reduce_batch_k<<<dim3((unsigned)nsplit, (unsigned)rb.n), 256, 0, s>>>(rb, ws);
+  AO_KERNEL_CHECK();
+  if (nsplit > 1) {
+    reduce_batch_fin_k<<<1, 64, 0, s>>>(rb, ws, nsplit);
+    AO_KERNEL_CHECK();
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -271,66 +378,107 @@ void row_solve(double* X, int64_t ldx, const double* RHS, int64_t ldr, const dou
 }
 
 // ---------------------------------------------------------------------------
-__global__ void sys_build_k(SysBuild sb) {
-  extern __shared__ double sh[];   // R*R
-  __shared__ double tr;
-  const int R = sb.R, RR = R * R;
-  for (int e = threadIdx.x; e < RR; e += blockDim.x) {
-    double c;
-    if (sb.ngram == 0) {
-      c = sb.Cpre[e];
-    } else {
-      c = 1.0;                                   // C = ones .* G_transp_G{j}...  (:98-103)
-      for (int k = 0; k < sb.ngram; ++k) c *= sb.grams[k][e];
+// One wave, thread t <-> row t of the R x R system, every matrix held in registers (fully unrolled,
+// RMAX >= R); values move between lanes with v_readlane broadcasts, so the R Cholesky steps cost a few
+// dozen cycles each instead of LDS round trips and barriers (this kernel is on the critical path of
+// every mode update: the 256-thread LDS version took ~60 us at R = 20, this one a few us).
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+template <int RMAX>
+__global__ __launch_bounds__(64) void sys_build_k(SysBuild sb) {
+  const int R = sb.R, t = threadIdx.x;
+  const bool mine = t < R;
+  double row[RMAX];                              // row t of C, then of B + nrho*rho/2*I, then of L
+  // all loads of one Gram matrix are issued together on clamped (always valid) addresses: one memory
+  // round trip per matrix instead of one per entry
+  {
+    const double* g0 = sb.ngram == 0 ? sb.Cpre : sb.grams[0];
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) row[c] = g0[(mine ? t : 0) + R * (c < R ? c : 0)];
+    for (int k = 1; k < sb.ngram; ++k) {         // C = ones .* G_transp_G{j}...  (:98-103)
+      const double* g = sb.grams[k];
+      double tmp[RMAX];
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) tmp[c] = g[(mine ? t : 0) + R * (c < R ? c : 0)];
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) row[c] *= tmp[c];
     }
-    sb.C[e] = c;
-    sh[e] = c;
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) {
+      if (mine && c < R) sb.C[t + R * c] = row[c];
+      else row[c] = 0.0;
+    }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int r = 0; r < R; ++r) t += sh[r + R * r];
-    tr = sb.rho_scale * (t / R);                 // rho = trace(C)/size(C,1)  (:115)
-    sb.rho[0] = tr;
+  double tr = 0.0;                               // diagonal summed in index order by every lane
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r)
+    if (r < R) tr += readlane_d(row[r], r);
+  const double rho = sb.rho_scale * (tr / R);    // rho = trace(C)/size(C,1)  (:115)
+  if (t == 0) sb.rho[0] = rho;
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c) {
+    double b = sb.w * row[c];                    // B = w*C (:116)
+    if (c == t) b += sb.ridge + sb.bsum_half;    // :117-119, :126
+    if (mine && c < R) sb.Bsys[t + R * c] = b;
+    if (c == t) b += sb.nrho * (rho / 2);        // :141 / :269-271
+    row[c] = (mine && c < R) ? b : 0.0;
   }
-  __syncthreads();
-  const double rho = tr;
-  for (int e = threadIdx.x; e < RR; e += blockDim.x) {
-    const int i = e % R, k = e / R;
-    double b = sb.w * sh[e];                     // B = w*C (:116)
-    if (i == k) b += sb.ridge + sb.bsum_half;    // :117-119, :126
-    sb.Bsys[e] = b;
-    if (i == k) b += sb.nrho * (rho / 2);        // :141 / :269-271
-    sh[e] = b;
-  }
-  __syncthreads();
-  const bool ok = chol_lds(sh, R);               // chol(B','lower') (:142); B symmetric
-  if (ok)
-    for (int e = threadIdx.x; e < RR; e += blockDim.x) sb.L[e] = sh[e];
-  if (ok && sb.Binv) {
-    // inv(L*L') column by column: forward then backward substitution on e_j.  The system matrix of
-    // an ADMM mode carries +rho/2*I with rho = trace(C)/R, so cond(B) <= 2R+1: the explicit inverse
-    // loses nothing measurable and turns the per-row solve into R independent dot products.
-    // Linv (lower) in a second LDS matrix: thread j owns column j (forward substitution on e_j),
-    // then Binv(i,j) = sum_{k >= max(i,j)} Linv(k,i)*Linv(k,j) with one thread per entry.
-    double* Li = sh + RR;
-    for (int j = threadIdx.x; j < R; j += blockDim.x) {
-      for (int i = 0; i < j; ++i) Li[i + R * j] = 0.0;
-      for (int i = j; i < R; ++i) {
-        double v = (i == j) ? 1.0 : 0.0;
-        for (int q = j; q < i; ++q) v -= sh[i + R * q] * Li[q + R * j];
-        Li[i + R * j] = v / sh[i + R * i];
+  // chol(B','lower') (:142), right-looking.  Lane t keeps L(t, 0..t); its entries right of the diagonal
+  // are never read by another lane.
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < RMAX; ++j) {
+    if (j < R && ok) {
+      const double d = readlane_d(row[j], j);
+      if (!(d > 0.0)) {
+        ok = false;
+      } else {
+        const double dj = sqrt(d);
+        const double lij = row[j] / dj;
+        row[j] = (t == j) ? dj : lij;
+#pragma unroll
+        for (int k = j + 1; k < RMAX; ++k)
+          if (k < R) row[k] -= lij * readlane_d(lij, k);
       }
     }
-    __syncthreads();
-    for (int e = threadIdx.x; e < RR; e += blockDim.x) {
-      const int i = e % R, j = e / R;
-      double acc = 0.0;
-      for (int k = (i > j ? i : j); k < R; ++k) acc += Li[k + R * i] * Li[k + R * j];
-      sb.Binv[e] = acc;
+  }
+  if (ok && mine) {
+#pragma unroll
+    for (int k = 0; k < RMAX; ++k)
+      if (k < R) sb.L[t + R * k] = (k <= t) ? row[k] : 0.0;
+  }
+  if (ok && sb.Binv) {
+    // inv(L*L'): the system matrix of an ADMM mode carries +rho/2*I with rho = trace(C)/R, so
+    // cond(B) <= 2R+1: the explicit inverse loses nothing measurable and turns the per-row solve into R
+    // independent dot products.  Lane t owns column t of X = inv(L) (forward substitution on e_t; entries
+    // above the diagonal come out as exact zeros), then Binv(i,t) = sum_k X(k,i)*X(k,t).
+    double xc[RMAX];
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      xc[i] = 0.0;
+      if (i < R) {
+        double v = (i == t) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < i; ++q) v -= readlane_d(row[q], i) * xc[q];
+        xc[i] = v / readlane_d(row[i], i);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+      if (i < R) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = i; k < RMAX; ++k)            // X(k,i) = 0 for k < i
+          if (k < R) acc += readlane_d(xc[k], i) * xc[k];
+        if (mine) sb.Binv[t + R * i] = acc;       // symmetric: stored as Binv(t,i), coalesced
+      }
     }
   }
-  if (threadIdx.x == 0 && sb.ctl) {
+  if (t == 0 && sb.ctl) {
     sb.ctl->active = 1;
     sb.ctl->iters = 0;
     if (!ok) sb.ctl->notpd = 1;
@@ -339,7 +487,12 @@ __global__ void sys_build_k(SysBuild sb) {
 }
 void sys_build(const SysBuild& sb, hipStream_t s) {
   AO_REQUIRE(sb.R >= 1 && sb.R <= kMaxRank, "sys_build: bad R");
-  sys_build_k<<<1, 256, (size_t)2 * sb.R * sb.R * sizeof(double), s>>>(sb);
+  static_assert(kMaxRank <= 64, "sys_build_k maps one lane to one row");
+  if (sb.R <= 8) sys_build_k<8><<<1, 64, 0, s>>>(sb);
+  else if (sb.R <= 16) sys_build_k<16><<<1, 64, 0, s>>>(sb);
+  else if (sb.R <= 20) sys_build_k<20><<<1, 64, 0, s>>>(sb);
+  else if (sb.R <= 32) sys_build_k<32><<<1, 64, 0, s>>>(sb);
+  else sys_build_k<64><<<1, 64, 0, s>>>(sb);
   AO_KERNEL_CHECK();
 }
 

@@ -36,7 +36,7 @@ struct CpBlock {
   int cached_mode = -1;
   uint64_t cached_version = 0;
   ContractPlan plan;
-  DevBuf T, frag, scratch, tmpA, tmpB;
+  DevBuf T, frag, scratch, ft, tmpA, tmpB;
 };
 
 struct ModeInfo {
@@ -151,6 +151,9 @@ class Engine {
   int device() const { return device_; }
 
   // MTTKRP of a dense block against factors (device), result scale*mttkrp into out (ld = ldOut)
+  void ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int R, bool use_cache, const int* update_seq,
+                          int nseq);
+  void prefetch_next_contraction(const aoadmm_options& opt);
   void block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
                     int64_t ldOut, bool use_cache, const int* update_seq, int nseq);
   void block_upload(CpBlock& b, int nd, const int64_t* dims, const double* host, int prec, int64_t row0,
@@ -197,7 +200,7 @@ class Engine {
   AdmmCtl* ctl_of_mode(int m) { return ctls_.as<AdmmCtl>() + m; }
   AdmmCtl* ctl_of_coupling(int c) { return ctls_.as<AdmmCtl>() + n_modes_ + c; }
   void timed_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
-                      void* frag, double* T);
+                      void* frag, void* T);
 };
 
 }  // namespace aoadmm

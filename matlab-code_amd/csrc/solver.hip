@@ -49,7 +49,8 @@ Engine::~Engine() {
 void Engine::comm_init(const char id[128], int rank, int world) {
   AO_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world %d/%d", rank, world);
   AO_HIP(hipSetDevice(device_));
-  if (world > 1) {
+  if (comm_) { (void)ncclCommDestroy(comm_); comm_ = nullptr; }
+  if (id != nullptr) {               // world == 1 with an id: one-rank communicator (exercises the RCCL path on one GPU)
     ncclUniqueId uid;
     static_assert(sizeof(uid) <= 128, "unique id larger than the ABI buffer");
     std::memcpy(&uid, id, sizeof(uid));
@@ -60,7 +61,7 @@ void Engine::comm_init(const char id[128], int rank, int world) {
 }
 
 void Engine::allreduce(double* buf, int64_t n) {
-  if (world_ <= 1 || n <= 0) return;
+  if (!comm_ || n <= 0) return;
   AO_NCCL(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, comm_, stream_));
 }
 
@@ -498,7 +499,7 @@ void Engine::state_get(int field, int index, int slab, double* host, int64_t row
 // MTTKRP engine
 // ---------------------------------------------------------------------------
 void Engine::timed_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
-                            void* frag, double* T) {
+                            void* frag, void* T) {
   KernelStats& ks = kstats_[pl.lead ? 1 : 0];
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (profile_ && ks.pending.size() < 100000) {
@@ -544,13 +545,67 @@ static int next_update_distance(int pos, int c, const int* seq, int n) {
   return n + 1;                              // never updated
 }
 
+// Tensor pass for a 3-way block: makes b.T hold the partial contraction that serves an MTTKRP for tensor
+// position `pos` (a cached one is reused while its factor is unchanged).
+void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int R, bool use_cache,
+                                const int* update_seq, int nseq) {
+  const int prec = b.X.prec;
+  const int64_t I = b.dims[0], Ip = b.X.pad0, J = b.dims[1], K = b.dims[2];
+  const bool hit = use_cache && b.cached_mode >= 0 && b.cached_mode != pos &&
+                   facs[b.cached_mode].version == b.cached_version;
+  if (hit) return;
+  // which mode to contract: any mode but `pos`; prefer the one whose factor stays unchanged longest so
+  // that the partial contraction also serves the next update (cycle 3->{1,2}, 2->{3,1}, 1->{2,3}:
+  // 1.5 tensor reads per outer iteration).  The leading mode needs the LDS-transposed kernel (fp32 only).
+  int c = -1, best = -1;
+  for (int cand = 2; cand >= 0; --cand) {
+    if (cand == pos) continue;
+    static const bool force_lead = getenv("AOADMM_FORCE_LEAD") != nullptr;   // development switch (tools/perf_mttkrp.py)
+    if (cand == 0 && !(prec == AOADMM_PREC_F32 && (use_cache || force_lead))) continue;
+    if (cand != 0 && force_lead && prec == AOADMM_PREC_F32 && pos != 0) continue;
+    const int dist = next_update_distance(pos, cand, update_seq, nseq);
+    if (dist > best) { best = dist; c = cand; }
+  }
+  ContractPlan pl;
+  const double* Fc = facs[c].p;
+  if (c == 2) pl = make_plan(1, 0, Ip * J, Ip * J, K, R, prec);
+  else if (c == 1) pl = make_plan(K, Ip * J, Ip, Ip, J, R, prec);
+  else { pl = make_lead_plan(J * K, Ip, I, R); Fc = facs[0].p + (comm_ ? b.row0 : 0); }
+  b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
+  timed_contract(b.X.data.p, prec, pl, Fc, facs[c].ld, b.frag.p, b.T.p);
+  b.cached_mode = c; b.cached_version = facs[c].version; b.plan = pl;
+}
+
+// The first tensor pass of the next outer iteration does not depend on the host's stopping decision, so
+// it is enqueued before the host waits for the objective values: the round trip hides behind it.
+void Engine::prefetch_next_contraction(const aoadmm_options& opt) {
+  if (!opt.use_dimtree) return;
+  for (int cid = -1; cid < n_couplings_; ++cid) {
+    for (int p = 0; p < n_tensors_; ++p)
+      for (int m = 0; m < n_modes_; ++m) {
+        const ModeInfo& mi = modes_[m];
+        if (mi.coupling != cid || mi.tensor != p) continue;
+        TensorInfo& t = tensors_[p];                      // first mode the next iteration updates
+        if (t.par2 || t.blk.nd != 3) return;
+        FactorRef facs[8];
+        for (int i = 0; i < t.nmodes; ++i) {
+          const ModeInfo& o = modes_[t.modes[i]];
+          facs[i] = FactorRef{o.fac.d(), o.rows, o.version};
+        }
+        std::vector<int> seq = update_sequence(p);
+        ensure_contraction(t.blk, mi.pos, facs, mi.R, true, seq.data(), (int)seq.size());
+        return;
+      }
+  }
+}
+
 void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
                           int64_t ldOut, bool use_cache, const int* update_seq, int nseq) {
   AO_REQUIRE(b.has_data, "tensor has no data");
   AO_REQUIRE(pos >= 0 && pos < b.nd, "mttkrp: mode %d out of range", pos);
   const int prec = b.X.prec;
   const int64_t I = b.dims[0], Ip = b.X.pad0;
-  const bool sharded = world_ > 1;
+  const bool sharded = comm_ != nullptr;
   double* out_local = out;
   const int64_t out_rows_full = (pos == 0) ? b.full0 : b.dims[pos];
   if (sharded && pos == 0) {
@@ -566,42 +621,19 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
     if (pos == 0) {
       ContractPlan pl = make_plan(1, 0, Ip, Ip, J, R, prec);
       b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
-      timed_contract(b.X.data.p, prec, pl, facs[1].p, facs[1].ld, b.frag.p, b.T.d());
-      launch_t_to_colmajor(b.T.d(), pl.nchunk, pl.trows(), I, R, scale, out_local, ldOut, stream_);
+      timed_contract(b.X.data.p, prec, pl, facs[1].p, facs[1].ld, b.frag.p, b.T.p);
+      launch_t_to_colmajor(b.T.p, pl.tprec, pl.nchunk, pl.trows(), I, R, scale, out_local, ldOut, stream_);
     } else {
       const int64_t Jp = b.Xt.pad0;
       ContractPlan pl = make_plan(1, 0, Jp, Jp, I, R, prec);
       b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
-      timed_contract(b.Xt.data.p, prec, pl, F0, facs[0].ld, b.frag.p, b.T.d());
-      launch_t_to_colmajor(b.T.d(), pl.nchunk, pl.trows(), J, R, scale, out_local, ldOut, stream_);
+      timed_contract(b.Xt.data.p, prec, pl, F0, facs[0].ld, b.frag.p, b.T.p);
+      launch_t_to_colmajor(b.T.p, pl.tprec, pl.nchunk, pl.trows(), J, R, scale, out_local, ldOut, stream_);
     }
     b.cached_mode = -1;
   } else if (b.nd == 3) {
     const int64_t J = b.dims[1], K = b.dims[2];
-    bool hit = use_cache && b.cached_mode >= 0 && b.cached_mode != pos &&
-               facs[b.cached_mode].version == b.cached_version;
-    if (!hit) {
-      // which mode to contract: any mode but `pos`; prefer the one whose factor stays unchanged longest so
-      // that the partial contraction also serves the next update (cycle 3->{1,2}, 2->{3,1}, 1->{2,3}:
-      // 1.5 tensor reads per outer iteration).  The leading mode needs the LDS-transposed kernel (fp32 only).
-      int c = -1, best = -1;
-      for (int cand = 2; cand >= 0; --cand) {
-        if (cand == pos) continue;
-        static const bool force_lead = getenv("AOADMM_FORCE_LEAD") != nullptr;   // development switch (tools/perf_mttkrp.py)
-        if (cand == 0 && !(prec == AOADMM_PREC_F32 && (use_cache || force_lead))) continue;
-        if (cand != 0 && force_lead && prec == AOADMM_PREC_F32 && pos != 0) continue;
-        const int dist = next_update_distance(pos, cand, update_seq, nseq);
-        if (dist > best) { best = dist; c = cand; }
-      }
-      ContractPlan pl;
-      const double* Fc = facs[c].p;
-      if (c == 2) pl = make_plan(1, 0, Ip * J, Ip * J, K, R, prec);
-      else if (c == 1) pl = make_plan(K, Ip * J, Ip, Ip, J, R, prec);
-      else { pl = make_lead_plan(J * K, Ip, I, R); Fc = F0; }
-      b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
-      timed_contract(b.X.data.p, prec, pl, Fc, facs[c].ld, b.frag.p, b.T.d());
-      b.cached_mode = c; b.cached_version = facs[c].version; b.plan = pl;
-    }
+    ensure_contraction(b, pos, facs, R, use_cache, update_seq, nseq);
     const int c = b.cached_mode;
     const ContractPlan& pl = b.plan;
     // T rows are (a + Apad*bb) with (a, bb) the two uncontracted modes in tensor order
@@ -611,12 +643,14 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
     const double* Fa = ia == 0 ? F0 : facs[1].p;
     if (pos == ia) {
       b.scratch.ensure(reduce_outer_scratch_bytes(An, Bn, R));
-      launch_reduce_outer(b.T.d(), pl.nchunk, pl.trows(), An, Apad, Bn, R, facs[ib].p, facs[ib].ld, scale,
-                          out_local, ldOut, b.scratch.d(), stream_);
+      b.ft.ensure(reduce_factor_scratch_bytes(Bn, R));
+      launch_reduce_outer(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, facs[ib].p, facs[ib].ld, scale,
+                          out_local, ldOut, b.scratch.d(), b.ft.d(), stream_);
     } else {
       AO_REQUIRE(pos == ib, "internal: cached contraction cannot serve this mode");
-      launch_reduce_inner(b.T.d(), pl.nchunk, pl.trows(), An, Apad, Bn, R, Fa, facs[ia].ld, scale, out_local, ldOut,
-                          stream_);
+      b.ft.ensure(reduce_factor_scratch_bytes(An, R));
+      launch_reduce_inner(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, Fa, facs[ia].ld, scale, out_local,
+                          ldOut, b.ft.d(), stream_);
     }
   } else {
     // N-way (N > 3): contract the last mode (or the one before it when pos is last), then fold the
@@ -650,7 +684,7 @@ void Engine::ensure_mode_work(ModeInfo& mi) {
   mi.gram.ensure(RR); mi.C.ensure(RR); mi.Bsys.ensure(RR); mi.L.ensure(RR); mi.Binv.ensure(RR);
   mi.rho.ensure(64);
   mi.Zold.ensure(nR); mi.V.ensure(nR); mi.Znew.ensure(nR); mi.RHS.ensure(nR); mi.TD.ensure(nR); mi.tmp.ensure(nR);
-  mi.part.ensure((size_t)admm_partials(mi.rows) * 4 * sizeof(double) + 64 * 4 * sizeof(double));
+  mi.part.ensure((size_t)admm_partials(mi.rows) * 4 * sizeof(double));
   if (mi.constrained) mi.proxws.ensure(prox_ws_bytes(mi.prox.type, mi.rows, mi.R));
   atbws_.ensure(atb_ws_bytes(mi.rows, mi.R, mi.R));
 }
@@ -711,9 +745,8 @@ void Engine::update_uncoupled_cp_mode(int m, const aoadmm_options& opt) {
     am.A = mi.Aeff; am.L = mi.L.d(); am.Binv = mi.Binv.d(); am.rho = mi.rho.d();
     am.fac = mi.fac.d(); am.Z = mi.Z.d(); am.mu = mi.mu.d();
     am.rows = mi.rows; am.R = mi.R; am.prox = mi.prox;
-    for (int it = 0; it < opt.MaxInnerIters; ++it)
-      admm_constrained_iteration(am, mi.part.d(), mi.V.d(), mi.Znew.d(), mi.proxws.d(), ctl, opt.MaxInnerIters,
-                                 opt.innerRelPrTol_constr, opt.innerRelDualTol_constr, stream_);
+    admm_constrained_loop(am, mi.part.d(), mi.V.d(), mi.Znew.d(), mi.proxws.d(), ctl, opt.MaxInnerIters,
+                          opt.innerRelPrTol_constr, opt.innerRelDualTol_constr, stream_);
   }
   compute_gram(mi);                                                           // :148
   mi.version++;
@@ -869,6 +902,12 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
 // ---------------------------------------------------------------------------
 void Engine::eval_objective_enqueue(bool first) {
   double* S = slots_.d();
+  ReduceBatch rb;                                  // every plain reduction of this evaluation in one launch
+  auto add = [&](int kind, double* slot, const double* x, const double* y, int64_t n) {
+    ReduceTask k;
+    k.kind = kind; k.slot = slot; k.x = x; k.y = y; k.n = n;
+    rb.add(k);
+  };
   for (int p = 0; p < n_tensors_; ++p) {
     TensorInfo& t = tensors_[p];
     if (t.par2) {
@@ -876,8 +915,8 @@ void Engine::eval_objective_enqueue(bool first) {
       if (!first && t.last_pos == 0) {           // shortcut through last_mttkrp / last_had (:1254-1260)
         ModeInfo& lm = modes_[t.modes[0]];
         double* sp = S + n_modes_ * kSlotsPerMode + 2 * p;
-        dot(sp + 0, lm.A.d(), lm.fac.d(), lm.rows * lm.R, redws_.d(), nullptr, stream_);
-        dot(sp + 1, lm.C.d(), lm.gram.d(), (int64_t)lm.R * lm.R, redws_.d(), nullptr, stream_);
+        add(RT_DOT, sp + 0, lm.A.d(), lm.fac.d(), lm.rows * lm.R);
+        add(RT_DOT, sp + 1, lm.C.d(), lm.gram.d(), (int64_t)lm.R * lm.R);
       }
       continue;
     }
@@ -901,28 +940,38 @@ void Engine::eval_objective_enqueue(bool first) {
     }
     ModeInfo& lm = modes_[t.modes[t.last_pos]];
     double* sp = S + n_modes_ * kSlotsPerMode + 2 * p;
-    dot(sp + 0, lm.A.d(), lm.fac.d(), lm.rows * lm.R, redws_.d(), nullptr, stream_);       // f_2 * w
-    dot(sp + 1, lm.C.d(), lm.gram.d(), (int64_t)lm.R * lm.R, redws_.d(), nullptr, stream_);  // f_3
+    add(RT_DOT, sp + 0, lm.A.d(), lm.fac.d(), lm.rows * lm.R);                 // f_2 * w
+    add(RT_DOT, sp + 1, lm.C.d(), lm.gram.d(), (int64_t)lm.R * lm.R);          // f_3
   }
   for (int m = 0; m < n_modes_; ++m) {
     ModeInfo& mi = modes_[m];
     if (mi.slabs) continue;                      // per-slab ratios come from par2_b_gaps
     double* sm = S + (int64_t)m * kSlotsPerMode;
     const int64_t nm = mi.rows * mi.R;
-    sumsq_diff(sm + 0, mi.fac.d(), nullptr, nm, redws_.d(), nullptr, stream_);
+    add(RT_SUMSQ_DIFF, sm + 0, mi.fac.d(), nullptr, nm);
     if (mi.constrained) {
-      sumsq_diff(sm + 1, mi.fac.d(), mi.Z.d(), nm, redws_.d(), nullptr, stream_);
+      add(RT_SUMSQ_DIFF, sm + 1, mi.fac.d(), mi.Z.d(), nm);
       const int ty = mi.prox.type;
-      if (ty == AOADMM_C_L1_REG || ty == AOADMM_C_L0_REG || ty == AOADMM_C_L2_REG || ty == AOADMM_C_RIDGE ||
-          ty == AOADMM_C_GL_SMOOTH || ty == AOADMM_C_TV)
+      if (ty == AOADMM_C_L2_REG) {
         reg_value(sm + 3, ty, mi.prox.p0, mi.fac.d(), mi.rows, mi.R, redws_.d(), stream_);
+      } else if (ty == AOADMM_C_L1_REG || ty == AOADMM_C_L0_REG || ty == AOADMM_C_RIDGE || ty == AOADMM_C_GL_SMOOTH ||
+                 ty == AOADMM_C_TV) {
+        ReduceTask k;
+        k.kind = RT_REG; k.aux = ty; k.slot = sm + 3; k.x = mi.fac.d(); k.rows = mi.rows; k.R = mi.R; k.scale = mi.prox.p0;
+        rb.add(k);
+      }
     }
     if (mi.coupling >= 0) {
       CouplingInfo& ci = couplings_[mi.coupling];
       coupling_image(mi.TD.d(), ci, ci.Delta.d(), mi, nullptr, stream_);
-      sumsq_diff(sm + 2, mi.fac.d(), mi.TD.d(), nm, redws_.d(), nullptr, stream_);
+      add(RT_SUMSQ_DIFF, sm + 2, mi.fac.d(), mi.TD.d(), nm);
+    }
+    if (rb.n >= kReduceBatchMax - 4) {           // many modes: flush and start the next batch
+      reduce_batch(rb, redws_.d(), stream_);
+      rb = ReduceBatch();
     }
   }
+  reduce_batch(rb, redws_.d(), stream_);
 }
 
 static bool stop_one(double f, double fo, const aoadmm_options& o) {
@@ -962,15 +1011,26 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     t.last_pos = 2;
   }
   const int nctl = n_modes_ + n_couplings_;
-  std::vector<AdmmCtl> hctl(nctl);
   const int nslots = n_modes_ * kSlotsPerMode + 2 * n_tensors_;
-  std::vector<double> hs(nslots);
+  // pinned landing area + event: the host waits for the objective values only, not for work enqueued
+  // behind them (prefetch_next_contraction)
+  struct Pinned {
+    void* p = nullptr; hipEvent_t ev = nullptr;
+    ~Pinned() { if (p) (void)hipHostFree(p); if (ev) (void)hipEventDestroy(ev); }
+  } pin;
+  AO_HIP(hipHostMalloc(&pin.p, nslots * sizeof(double) + nctl * sizeof(AdmmCtl), hipHostMallocDefault));
+  AO_HIP(hipEventCreateWithFlags(&pin.ev, hipEventDisableTiming));
+  double* hs = static_cast<double*>(pin.p);
+  AdmmCtl* hctl = reinterpret_cast<AdmmCtl*>(hs + nslots);
 
   bool eval_first = true;
+  auto enqueue_readback = [&]() {
+    AO_HIP(hipMemcpyAsync(hs, slots_.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    AO_HIP(hipMemcpyAsync(hctl, ctls_.p, nctl * sizeof(AdmmCtl), hipMemcpyDeviceToHost, stream_));
+    AO_HIP(hipEventRecord(pin.ev, stream_));
+  };
   auto finish_eval = [&](double f[4]) {
-    AO_HIP(hipMemcpyAsync(hs.data(), slots_.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    AO_HIP(hipMemcpyAsync(hctl.data(), ctls_.p, nctl * sizeof(AdmmCtl), hipMemcpyDeviceToHost, stream_));
-    AO_HIP(hipStreamSynchronize(stream_));
+    AO_HIP(hipEventSynchronize(pin.ev));
     for (int i = 0; i < nctl; ++i)
       if (hctl[i].notpd)
         throw Error(AOADMM_ERR_NOT_PD, "Cholesky failed: system matrix is not positive definite (chol in cmtf_fun_AOADMM.m:142/273/362)");
@@ -978,7 +1038,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     int ncon = 0;
     for (int p = 0; p < n_tensors_; ++p) {
       TensorInfo& t = tensors_[p];
-      const double* sp = hs.data() + n_modes_ * kSlotsPerMode + 2 * p;
+      const double* sp = hs + n_modes_ * kSlotsPerMode + 2 * p;
       if (t.par2) {
         Par2Block& b = t.p2;
         std::vector<double> res(b.K), q((size_t)b.K * 4);
@@ -1022,7 +1082,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     for (int m = 0; m < n_modes_; ++m) {
       const ModeInfo& mi = modes_[m];
       if (mi.slabs) continue;
-      const double* sm = hs.data() + (int64_t)m * kSlotsPerMode;
+      const double* sm = hs + (int64_t)m * kSlotsPerMode;
       const double nf = std::sqrt(sm[0]);
       if (mi.constrained) {
         const int ty = mi.prox.type;
@@ -1045,6 +1105,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
 
   double f[4], fo[4];
   eval_objective_enqueue(true);                                                // :32
+  enqueue_readback();
   finish_eval(f);
   eval_first = false;
   if (out->func_val_conv) out->func_val_conv[0] = f[0];
@@ -1080,6 +1141,8 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     }
     for (int i = 0; i < 4; ++i) fo[i] = f[i];
     eval_objective_enqueue(false);                                             // :447
+    enqueue_readback();
+    if (iter < opt.MaxOuterIters) prefetch_next_contraction(opt);
     finish_eval(f);
     if (out->func_val_conv) out->func_val_conv[iter] = f[0];
     if (out->func_coupl_conv) out->func_coupl_conv[iter] = f[1];

