@@ -205,9 +205,13 @@ __global__ __launch_bounds__(256) void contract_f32(KArgs a) {
 // Here the reduction index is the contiguous one, so MFMA A operands (one unfolding row per lane)
 // cannot be loaded straight from HBM: a workgroup streams a [128 rows m] x [64 i] tile (128 segments
 // of 256 contiguous bytes) through registers into LDS (row stride 68 floats: ds_read_b128 of 16 rows at
-// one column offset hits 16 distinct 16-byte slots), and each wave feeds its 32 rows to
-// v_mfma_f32_32x32x2_f32 from ds_read_b128 (4 consecutive i per lane = 4 MFMA k-steps).  The loads of
-// chunk c+1 are in flight while chunk c is consumed; one barrier per chunk (double-buffered LDS).
+// one column offset hits 16 distinct 16-byte slots).  The four waves split the REDUCTION, not the rows:
+// wave w multiplies all 128 rows by i in [16w, 16w+16) of every chunk (ds_read_b128 = 4 consecutive i per
+// lane = 4 k-steps of v_mfma_f32_32x32x2_f32), so one B fragment serves four row tiles and B traffic is a
+// quarter of the tensor traffic (with rows split over waves it equalled it and the kernel ran 25 %
+// slower).  The four partial 128 x 32 tiles are summed through LDS at the end and written as one
+// contiguous block of T.  Loads of chunks c+2 / c+3 are in flight while chunk c is consumed; one barrier per
+// chunk (double-buffered LDS).
 // B fragments are packed so that lane (h, col) finds F[8g + 4h + t][col] for t = 0..3 in one float4.
 static constexpr int kLeadRows = 128;   // unfolding rows per workgroup
 static constexpr int kLeadKC = 64;      // reduction elements per chunk
@@ -239,7 +243,7 @@ struct LArgs {
 };
 
 template <int NT>
-__global__ __launch_bounds__(256) void contract_lead_f32(LArgs a) {
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void contract_lead_f32(LArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][kLeadRows][kLeadStride]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * kLeadRows;
@@ -258,11 +262,13 @@ __global__ __launch_bounds__(256) void contract_lead_f32(LArgs a) {
     rowp[q] = a.X + m * a.ld;
   }
   const int64_t last4 = a.ld - 4;                    // last 16-byte aligned group inside a row
-  f32x16 acc[NT];
+  f32x16 acc[NT][4];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nt][tl][i] = 0.f;
   const int r32 = lane & 31, h = lane >> 5;
   const f32x4* fbase = reinterpret_cast<const f32x4*>(a.frag) + lane;
   const int64_t fnt = a.Cg * 64;
@@ -282,31 +288,44 @@ __global__ __launch_bounds__(256) void contract_lead_f32(LArgs a) {
     _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                 \
       *reinterpret_cast<f32x4*>(base_ + (srow + 16 * q_) * kLeadStride + scol) = ST[q_];             \
   }
-  // consume chunk CH from LDS buffer BUF; if PF, refill register set ST with chunk CHN meanwhile
-#define AO_LEAD_COMPUTE(BUF, CH, ST, CHN, PF)                                                        \
+  // B fragments of this wave's two 8-i groups, fetched one chunk ahead (their L2 latency would otherwise
+  // stall the wave at the head of every chunk: 32 MFMAs = 0.85 us of work per chunk cannot hide it)
+  f32x4 fA[NT][2], fB[NT][2];
+#define AO_LEAD_FRAG(FV, CH)                                                                         \
   {                                                                                                  \
-    const float* xs_ = lds + (BUF) * (kLeadRows * kLeadStride) + (32 * w + r32) * kLeadStride + 4 * h; \
-    f32x4 xv_[kLeadKC / 8], fv_[NT][kLeadKC / 8];                                                    \
-    _Pragma("unroll") for (int g = 0; g < kLeadKC / 8; ++g) {          /* all operands of the chunk up front */ \
-      int64_t gg = (CH) * (kLeadKC / 8) + g;                                                         \
-      if (gg >= a.Cg) gg = a.Cg - 1;                                   /* ragged last chunk: masked below */ \
-      xv_[g] = *reinterpret_cast<const f32x4*>(xs_ + 8 * g);                                         \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) fv_[nt][g] = fbase[nt * fnt + gg * 64];      \
+    _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2) {                                               \
+      int64_t gg = (CH) * (kLeadKC / 8) + 2 * w + g2;                                                \
+      if (gg >= a.Cg) gg = a.Cg - 1;                                   /* ragged last chunk: masked in COMPUTE */ \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) FV[nt][g2] = fbase[nt * fnt + gg * 64];      \
     }                                                                                                \
-    __builtin_amdgcn_sched_barrier(0);                                                               \
-    _Pragma("unroll") for (int g = 0; g < kLeadKC / 8; ++g) {                                        \
-      if ((CH) * (kLeadKC / 8) + g < a.Cg) {                                                         \
-        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                            \
-          _Pragma("unroll") for (int t = 0; t < 4; ++t)                                              \
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv_[g][t], fv_[nt][g][t], acc[nt], 0, 0, 0); \
-      }                                                                                              \
-      if (PF) AO_LEAD_LOAD1(ST, CHN, g)                                                              \
+  }
+  // consume this wave's 16 i of chunk CH (B fragments FV) from LDS buffer BUF; meanwhile fetch the next
+  // chunk's fragments into FVN (if NF) and refill register set ST with chunk CHN (if PF)
+#define AO_LEAD_COMPUTE(BUF, CH, FV, FVN, NF, ST, CHN, PF)                                           \
+  {                                                                                                  \
+    const float* xs_ = lds + (BUF) * (kLeadRows * kLeadStride) + r32 * kLeadStride + 16 * w + 4 * h; \
+    if (NF) AO_LEAD_FRAG(FVN, (CH) + 1)                                                              \
+    _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2) {                                               \
+      f32x4 xv_[4];                                                                                  \
+      const bool live_ = (CH) * (kLeadKC / 8) + 2 * w + g2 < a.Cg;                                   \
+      _Pragma("unroll") for (int tl = 0; tl < 4; ++tl)                                               \
+        xv_[tl] = *reinterpret_cast<const f32x4*>(xs_ + 32 * tl * kLeadStride + 8 * g2);            \
       __builtin_amdgcn_sched_barrier(0);                                                             \
+      _Pragma("unroll") for (int tl = 0; tl < 4; ++tl) {                                             \
+        if (live_) {                                                                                 \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                          \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                            \
+              acc[nt][tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv_[tl][t], FV[nt][g2][t], acc[nt][tl], 0, 0, 0); \
+        }                                                                                            \
+        if (PF) AO_LEAD_LOAD1(ST, CHN, 4 * g2 + tl)                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+      }                                                                                              \
     }                                                                                                \
   }
   const int64_t n = c1 > c0 ? c1 - c0 : 0;
   if (n > 0) {
     AO_LEAD_LOAD(sA, c0)
+    AO_LEAD_FRAG(fA, c0)
     AO_LEAD_WRITE(sA, 0)
   }
   if (n > 1) AO_LEAD_LOAD(sA, c0 + 1)
@@ -314,31 +333,48 @@ __global__ __launch_bounds__(256) void contract_lead_f32(LArgs a) {
   __syncthreads();
   for (int64_t k = 0; k < n; k += 2) {
     if (k + 1 < n) AO_LEAD_WRITE(sA, 1)
-    if (k + 3 < n) AO_LEAD_COMPUTE(0, c0 + k, sA, c0 + k + 3, true)
-    else AO_LEAD_COMPUTE(0, c0 + k, sA, c0, false)
+    if (k + 3 < n) AO_LEAD_COMPUTE(0, c0 + k, fA, fB, true, sA, c0 + k + 3, true)
+    else if (k + 1 < n) AO_LEAD_COMPUTE(0, c0 + k, fA, fB, true, sA, c0, false)
+    else AO_LEAD_COMPUTE(0, c0 + k, fA, fB, false, sA, c0, false)
     __syncthreads();
     if (k + 1 >= n) break;
     if (k + 2 < n) AO_LEAD_WRITE(sB, 0)
-    if (k + 4 < n) AO_LEAD_COMPUTE(1, c0 + k + 1, sB, c0 + k + 4, true)
-    else AO_LEAD_COMPUTE(1, c0 + k + 1, sB, c0, false)
+    if (k + 4 < n) AO_LEAD_COMPUTE(1, c0 + k + 1, fB, fA, true, sB, c0 + k + 4, true)
+    else if (k + 2 < n) AO_LEAD_COMPUTE(1, c0 + k + 1, fB, fA, true, sB, c0, false)
+    else AO_LEAD_COMPUTE(1, c0 + k + 1, fB, fA, false, sB, c0, false)
     __syncthreads();
   }
+#undef AO_LEAD_FRAG
 #undef AO_LEAD_LOAD1
 #undef AO_LEAD_LOAD
 #undef AO_LEAD_WRITE
 #undef AO_LEAD_COMPUTE
-  float* Tc = a.T + (int64_t)slice * a.M * a.R;
+  // sum the four waves' partial tiles through LDS (region w: [128 rows][33], column-padded), then write
+  // the 128 x R block of T, which is contiguous in memory, with flat coalesced stores
+  __syncthreads();
+  constexpr int kEpiStride = 33;
+  float* Tc = a.T + (int64_t)slice * a.M * a.R + m0 * a.R;
+  const int64_t rows_here = (a.M - m0 < kLeadRows) ? (a.M - m0) : kLeadRows;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int r = 32 * nt + r32;
-    if (r < a.R) {
+    float* reg = lds + w * (kLeadRows * kEpiStride);
+#pragma unroll
+    for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int rho = (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int64_t m = m0 + 32 * w + rho;
-        if (m < a.M) Tc[m * a.R + r] = acc[nt][i];
+        reg[(32 * tl + rho) * kEpiStride + r32] = acc[nt][tl][i];
       }
+    __syncthreads();
+    const int ncol = (a.R - 32 * nt < 32) ? (a.R - 32 * nt) : 32;      // columns of this N tile
+    const int total = (int)rows_here * ncol;
+    for (int e = tid; e < total; e += 256) {
+      const int row = e / ncol, col = e - row * ncol;
+      const float* p = lds + row * kEpiStride + col;
+      const float v = (p[0] + p[kLeadRows * kEpiStride]) + (p[2 * kLeadRows * kEpiStride] + p[3 * kLeadRows * kEpiStride]);
+      Tc[(int64_t)row * a.R + 32 * nt + col] = v;
     }
+    __syncthreads();
   }
 }
 
