@@ -200,6 +200,216 @@ __global__ __launch_bounds__(256) void contract_f32(KArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// f32 contraction, 16-column tiles: v_mfma_f32_16x16x4_f32 for the first 16*NT columns of the factor and,
+// when the rank leaves 1..4 columns over (R = 20: the headline configuration), packed-fp32 VALU FMAs for
+// those instead of a second, mostly empty MFMA tile.  At R = 20 the 32x32x2 form issues 32 columns of
+// matrix work per tensor element; this kernel issues 16 on the matrix pipe + 4 on the vector pipe, which
+// halves the matrix-pipe time the streaming loads have to overlap with.
+//   A operand: lane l holds A[row l&15][k = l>>4]; a lane's float4 load gives rows 4*(l&15)+v of column
+//   c + (l>>4): MFMA row tile (half, v) holds rows 64*half + 4*j + v, j = 0..15.
+//   B operand: lane l holds F[c + (l>>4)][16nt + (l&15)]  (packed float2 per 8-column group: kk = 0, 1).
+//   Extra columns: lane l multiplies its four rows by F[c + (l>>4)][16NT + e], e = 0..3 (one float4 per
+//   4-column group, shared by the 16 lanes of a quarter wave); the four k-quarters are added at the end.
+// ---------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// main: frag[nt][g][lane] float2 = F[8g + 4kk + (lane>>4)][16nt + (lane&15)], kk = 0,1
+// extra (after the main block): fe[g][kk][q] float4 = F[8g + 4kk + q][16NT + e], e = 0..3
+__global__ void pack_frag16_f32(const double* __restrict__ F, int64_t ldF, int64_t C, int R, int NT, int EX,
+                                int64_t Cg, float* __restrict__ frag) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nmain = (int64_t)NT * Cg * 128;
+  if (idx < nmain) {
+    const int kk = idx & 1;
+    const int lane = (idx >> 1) & 63;
+    const int64_t g = (idx >> 7) % Cg;
+    const int nt = (int)((idx >> 7) / Cg);
+    const int64_t c = 8 * g + 4 * kk + (lane >> 4);
+    const int r = 16 * nt + (lane & 15);
+    frag[idx] = (c < C && r < R) ? (float)F[c + ldF * r] : 0.f;
+  } else if (EX && idx < nmain + Cg * 32) {
+    const int64_t j = idx - nmain;
+    const int e = j & 3, q = (j >> 2) & 3, kk = (j >> 4) & 1;
+    const int64_t g = j >> 5;
+    const int64_t c = 8 * g + 4 * kk + q;
+    const int r = 16 * NT + e;
+    frag[idx] = (c < C && r < R) ? (float)F[c + ldF * r] : 0.f;
+  }
+}
+
+template <int NT, bool EX>
+__global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract16_f32(KArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wt >= a.ntiles) return;                       // wave-uniform
+  const int chunk = blockIdx.y;
+  const int64_t b = wt / a.tiles_per_batch;
+  const int64_t m0 = (wt - b * a.tiles_per_batch) * kTileRows;
+  const int r16 = lane & 15, q = lane >> 4;
+  int64_t row0 = m0 + 4 * r16, row1 = m0 + 64 + 4 * r16;
+  if (row0 >= a.M) row0 = m0;                        // padding lanes re-read a valid row; never stored
+  if (row1 >= a.M) row1 = m0;
+  const int64_t g0 = (int64_t)chunk * a.groups_per_chunk;
+  int64_t g1 = g0 + a.groups_per_chunk;
+  if (g1 > a.Cg) g1 = a.Cg;
+  const int64_t gfull = (a.C / kGroup < g1) ? a.C / kGroup : g1;   // groups with all 8 columns valid
+  const float* X = reinterpret_cast<const float*>(a.X) + b * a.batch_stride;
+  const float* xp0 = X + row0 + (kGroup * g0 + q) * a.ld;
+  const float* xp1 = X + row1 + (kGroup * g0 + q) * a.ld;
+  const int64_t ld4 = 4 * a.ld;
+  const f32x2* fp = reinterpret_cast<const f32x2*>(a.frag) + g0 * 64 + lane;
+  const int64_t fnt = a.Cg * 64;                     // float2 stride between N tiles
+  const f32x4* fe = reinterpret_cast<const f32x4*>(reinterpret_cast<const f32x2*>(a.frag) + (int64_t)NT * a.Cg * 64) + g0 * 8 + q;
+
+  f32x4 acc[NT][2][4];
+  f32x2 accE[2][4][2];                                // [half][v][column pair]
+  // in-place packed FMA with the low / high float of X broadcast to both halves
+#define AO_PKFMA_LO(ACC, X2, E2) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(ACC) : "v"(X2), "v"(E2));
+#define AO_PKFMA_HI(ACC, X2, E2) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(ACC) : "v"(X2), "v"(E2));
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      accE[h][v][0] = f32x2{0.f, 0.f};
+      accE[h][v][1] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt][h][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+  // register ring of three 8-column stages; x index s = 2*kk + half
+  f32x4 x0[4], x1[4], x2[4], e0[2], e1[2], e2[2];
+  f32x2 f0[NT], f1[NT], f2[NT];
+  const int64_t ng = gfull > g0 ? gfull - g0 : 0;
+  const int64_t gstep = kGroup * a.ld;
+#define AO_LOAD1(XS, GI, S)                                                                          \
+  XS[S] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>((((S) & 1) ? xp1 : xp0) + (GI) * gstep + ((S) >> 1) * ld4));
+#define AO_LOADF(FS, ES, GI)                                                                         \
+  {                                                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) FS[nt] = fp[(GI) * 64 + nt * fnt];            \
+    if (EX) { ES[0] = fe[(GI) * 8]; ES[1] = fe[(GI) * 8 + 4]; }                                      \
+  }
+#define AO_LOAD_STAGE(XS, FS, ES, GI)                                                                \
+  { AO_LOAD1(XS, GI, 0) AO_LOAD1(XS, GI, 1) AO_LOAD1(XS, GI, 2) AO_LOAD1(XS, GI, 3) AO_LOADF(FS, ES, GI) }
+#define AO_FMA_S(XS, FS, ES, S)                                                                      \
+  {                                                                                                  \
+    _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                  \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                              \
+        acc[nt][(S) & 1][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(XS[S][v], FS[nt][(S) >> 1], acc[nt][(S) & 1][v], 0, 0, 0); \
+    }                                                                                                \
+    if (EX) {      /* accE[half][v][0..3] += x[v] * e[0..3]: two packed FMAs per row, x broadcast by op_sel */ \
+      const f32x2 xlo_ = __builtin_shufflevector(XS[S], XS[S], 0, 1), xhi_ = __builtin_shufflevector(XS[S], XS[S], 2, 3); \
+      const f32x2 ea_ = __builtin_shufflevector(ES[(S) >> 1], ES[(S) >> 1], 0, 1);                   \
+      const f32x2 eb_ = __builtin_shufflevector(ES[(S) >> 1], ES[(S) >> 1], 2, 3);                   \
+      AO_PKFMA_LO(accE[(S) & 1][0][0], xlo_, ea_) AO_PKFMA_LO(accE[(S) & 1][0][1], xlo_, eb_)        \
+      AO_PKFMA_HI(accE[(S) & 1][1][0], xlo_, ea_) AO_PKFMA_HI(accE[(S) & 1][1][1], xlo_, eb_)        \
+      AO_PKFMA_LO(accE[(S) & 1][2][0], xhi_, ea_) AO_PKFMA_LO(accE[(S) & 1][2][1], xhi_, eb_)        \
+      AO_PKFMA_HI(accE[(S) & 1][3][0], xhi_, ea_) AO_PKFMA_HI(accE[(S) & 1][3][1], xhi_, eb_)        \
+    }                                                                                                \
+  }
+#define AO_COMPUTE_STAGE(XS, FS, ES) { AO_FMA_S(XS, FS, ES, 0) AO_FMA_S(XS, FS, ES, 1) AO_FMA_S(XS, FS, ES, 2) AO_FMA_S(XS, FS, ES, 3) }
+  // consume stage (XC,FC,EC) while fetching stage GI into (XL,FL,EL): one load between MFMA groups
+#define AO_MIX_STAGE(XC, FC, EC, XL, FL, EL, GI)                                                     \
+  {                                                                                                  \
+    AO_FMA_S(XC, FC, EC, 0) AO_LOAD1(XL, GI, 0) __builtin_amdgcn_sched_barrier(0);                   \
+    AO_FMA_S(XC, FC, EC, 1) AO_LOAD1(XL, GI, 1) __builtin_amdgcn_sched_barrier(0);                   \
+    AO_FMA_S(XC, FC, EC, 2) AO_LOAD1(XL, GI, 2) __builtin_amdgcn_sched_barrier(0);                   \
+    AO_FMA_S(XC, FC, EC, 3) AO_LOAD1(XL, GI, 3) AO_LOADF(FL, EL, GI) __builtin_amdgcn_sched_barrier(0); \
+  }
+  if (ng > 0) AO_LOAD_STAGE(x0, f0, e0, 0)
+  if (ng > 1) AO_LOAD_STAGE(x1, f1, e1, 1)
+  int64_t g = 0;
+  for (; g + 5 <= ng; g += 3) {                      // steady state: every prefetch is in range
+    AO_MIX_STAGE(x0, f0, e0, x2, f2, e2, g + 2)
+    AO_MIX_STAGE(x1, f1, e1, x0, f0, e0, g + 3)
+    AO_MIX_STAGE(x2, f2, e2, x1, f1, e1, g + 4)
+  }
+  for (; g + 3 <= ng; g += 3) {                      // at most one drained round
+    if (g + 2 < ng) AO_LOAD_STAGE(x2, f2, e2, g + 2)
+    AO_COMPUTE_STAGE(x0, f0, e0)
+    if (g + 3 < ng) AO_LOAD_STAGE(x0, f0, e0, g + 3)
+    AO_COMPUTE_STAGE(x1, f1, e1)
+    if (g + 4 < ng) AO_LOAD_STAGE(x1, f1, e1, g + 4)
+    AO_COMPUTE_STAGE(x2, f2, e2)
+  }
+  if (g < ng) AO_COMPUTE_STAGE(x0, f0, e0)
+  if (g + 1 < ng) AO_COMPUTE_STAGE(x1, f1, e1)
+  g = gfull > g0 ? gfull : g0;
+  // ragged tail group: columns >= C are clamped (finite data) and meet zero B fragments
+  if (g < g1) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      int64_t c = kGroup * g + 4 * (s >> 1) + q;
+      if (c >= a.C) c = a.C - 1;
+      x0[s] = *reinterpret_cast<const f32x4*>(X + ((s & 1) ? row1 : row0) + c * a.ld);
+    }
+    {
+      const f32x2* fpt = reinterpret_cast<const f32x2*>(a.frag) + g * 64 + lane;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) f0[nt] = fpt[nt * fnt];
+      if (EX) {
+        const f32x4* fet = reinterpret_cast<const f32x4*>(reinterpret_cast<const f32x2*>(a.frag) + (int64_t)NT * a.Cg * 64) + g * 8 + q;
+        e0[0] = fet[0]; e0[1] = fet[4];
+      }
+    }
+    AO_COMPUTE_STAGE(x0, f0, e0)
+  }
+#undef AO_PKFMA_LO
+#undef AO_PKFMA_HI
+#undef AO_LOAD1
+#undef AO_LOADF
+#undef AO_LOAD_STAGE
+#undef AO_FMA_S
+#undef AO_COMPUTE_STAGE
+#undef AO_MIX_STAGE
+  // epilogue: 16x16 C/D map col = lane&15, row j = 4*(lane>>4) + reg; tile (half, v) row j is
+  // unfolding row m0 + 64*half + 4*j + v
+  float* Tc = reinterpret_cast<float*>(a.T) + ((int64_t)chunk * a.trows + b * a.M) * a.R;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r = 16 * nt + r16;
+    if (r < a.R) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int64_t m = m0 + 64 * h + 4 * (4 * q + i) + v;
+            if (m < a.M) Tc[m * a.R + r] = acc[nt][h][v][i];
+          }
+    }
+  }
+  if (EX) {
+    // add the four k-quarters (lanes l, l^16, l^32, l^48 hold the same rows), quarter 0 stores
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = accE[h][v][e >> 1][e & 1];
+          t += __shfl_xor(t, 16);
+          t += __shfl_xor(t, 32);
+          accE[h][v][e >> 1][e & 1] = t;
+        }
+    if (q == 0) {
+      const int ne = a.R - 16 * NT;                  // 1..4 live extra columns
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int64_t m = m0 + 64 * h + 4 * r16 + v;
+          if (m < a.M) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (e < ne) Tc[m * a.R + 16 * NT + e] = accE[h][v][e >> 1][e & 1];
+          }
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // f32 contraction of the LEADING (contiguous) mode:  T(m, r) = sum_i X[i + ld*m] * F(i, r)
 // ---------------------------------------------------------------------------
 // Here the reduction index is the contiguous one, so MFMA A operands (one unfolding row per lane)
@@ -470,7 +680,8 @@ static int nt_of(int R, int prec) {
 
 size_t ContractPlan::frag_bytes(int prec) const {
   const int64_t Cg = cdiv(C, kGroup);
-  return (size_t)nt_of(R, prec) * Cg * 1024;
+  // f32: the 32-column layout needs nt32*1024 B per group, the 16-column layout nt16*512 + 128 (extras)
+  return (size_t)(nt_of(R, prec) * 1024 + 1152) * Cg;
 }
 
 ContractPlan make_plan(int64_t nbatch, int64_t batch_stride, int64_t M, int64_t ld, int64_t C, int R,
@@ -560,6 +771,25 @@ void launch_contract(const void* X, int prec, const ContractPlan& pl, const doub
   AO_REQUIRE(cdiv(a.ntiles, 4) < (int64_t)2147483647, "tensor too large for one launch");
   if (prec == AOADMM_PREC_F32) {
     AO_REQUIRE(pl.ld % 4 == 0 && pl.M % 4 == 0 && pl.batch_stride % 4 == 0, "f32 layout must be padded to 4");
+    static const bool use32 = getenv("AOADMM_CONTRACT_32") != nullptr;   // development switch: 32x32x2 kernel
+    if (!use32) {
+      // 16-column tiles; 1..4 leftover columns go to the vector pipe
+      const int rem = pl.R % 16;
+      const bool ex = pl.R > 16 && rem >= 1 && rem <= 4;
+      const int nt16 = ex ? pl.R / 16 : (pl.R + 15) / 16;
+      const int64_t total = (int64_t)nt16 * Cg * 128 + (ex ? Cg * 32 : 0);
+      pack_frag16_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, nt16, ex ? 1 : 0, Cg, (float*)frag_ws);
+      AO_KERNEL_CHECK();
+      if (ev0) AO_HIP(hipEventRecord(ev0, s));
+      if (nt16 == 1 && !ex) contract16_f32<1, false><<<grid, 256, 0, s>>>(a);
+      else if (nt16 == 1) contract16_f32<1, true><<<grid, 256, 0, s>>>(a);
+      else if (nt16 == 2 && !ex) contract16_f32<2, false><<<grid, 256, 0, s>>>(a);
+      else if (nt16 == 2) contract16_f32<2, true><<<grid, 256, 0, s>>>(a);
+      else if (nt16 == 3 && !ex) contract16_f32<3, false><<<grid, 256, 0, s>>>(a);
+      else if (nt16 == 3) contract16_f32<3, true><<<grid, 256, 0, s>>>(a);
+      else if (nt16 == 4) contract16_f32<4, false><<<grid, 256, 0, s>>>(a);
+      else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
+    } else {
     int64_t total = (int64_t)NT * Cg * 256;
     pack_frag_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (float*)frag_ws);
     AO_KERNEL_CHECK();
@@ -570,6 +800,7 @@ void launch_contract(const void* X, int prec, const ContractPlan& pl, const doub
     else if (NT == 1) contract_f32<1, 4><<<grid, 256, 0, s>>>(a);
     else if (NT == 2) contract_f32<2, 4><<<grid, 256, 0, s>>>(a);
     else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
+    }
   } else {
     AO_REQUIRE(pl.ld % 2 == 0 && pl.M % 2 == 0 && pl.batch_stride % 2 == 0, "f64 layout must be padded to 2");
     int64_t total = (int64_t)NT * Cg * 128;
