@@ -589,6 +589,163 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void contract_lead_f32(LArgs 
 }
 
 // ---------------------------------------------------------------------------
+// Leading-mode contraction with 16-column tiles (same idea as contract16_f32): wave w multiplies all 128
+// rows of the staged tile by the 16 i of its slice with v_mfma_f32_16x16x4_f32 (lane (j, q) holds row
+// 16*tile + j, reduction index 4q + t in step t of its ds_read_b128).  Half the matrix-pipe work of the
+// 32-column form at R <= 16.  (Leftover columns on the vector pipe, as in contract16_f32, did not pay here:
+// the staging registers leave no room for the extra accumulators -- 6.4-6.8 ms against 6.2 ms for a second
+// MFMA tile at R = 20.)
+//   frag[nt][g16][lane] float4, component t = F[16 g16 + 4(lane>>4) + t][16nt + (lane&15)]
+// ---------------------------------------------------------------------------
+__global__ void pack_frag_lead16_f32(const double* __restrict__ F, int64_t ldF, int64_t C, int R, int NT,
+                                     int64_t Cg16, float* __restrict__ frag) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nmain = (int64_t)NT * Cg16 * 256;
+  if (idx < nmain) {
+    const int t = idx & 3;
+    const int lane = (idx >> 2) & 63;
+    const int64_t g = (idx >> 8) % Cg16;
+    const int nt = (int)((idx >> 8) / Cg16);
+    const int64_t c = 16 * g + 4 * (lane >> 4) + t;
+    const int r = 16 * nt + (lane & 15);
+    frag[idx] = (c < C && r < R) ? (float)F[c + ldF * r] : 0.f;
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract_lead16_f32(LArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][kLeadRows][kLeadStride]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * kLeadRows;
+  const int slice = blockIdx.y;
+  const int64_t nchunks_total = (a.C + kLeadKC - 1) / kLeadKC;
+  const int64_t c0 = (int64_t)slice * a.chunks_per_slice;
+  int64_t c1 = c0 + a.chunks_per_slice;
+  if (c1 > nchunks_total) c1 = nchunks_total;
+  const int64_t Cg16 = (a.C + 15) / 16;               // the packed fragments hold Cg16 + 1 groups, the last all zero
+  // staging map: 8 x 16-byte loads per thread, thread -> (row = (tid>>4) + 16q, 4 floats at 4*(tid&15))
+  const int srow = tid >> 4, scol = 4 * (tid & 15);
+  // row q of this thread is m0 + srow + 16q, clamped to the last row in the tail tile (re-read, never
+  // stored).  The eight row pointers are rebuilt at every load from one base and an opaque copy of the row
+  // stride (otherwise the compiler hoists them: 16 VGPRs this kernel does not have)
+  const unsigned mlast = (unsigned)((a.M - 1 - m0 < kLeadRows - 1) ? (a.M - 1 - m0) : (kLeadRows - 1));
+  const float* xblk = a.X + m0 * a.ld;
+  const int64_t last4 = a.ld - 4;                    // last 16-byte aligned group inside a row
+  f32x4 acc[NT][8];
+#pragma unroll
+  for (int tl = 0; tl < 8; ++tl)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt][tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const f32x4* fbase = reinterpret_cast<const f32x4*>(a.frag) + lane;
+  const int64_t fnt = (Cg16 + 1) * 64;
+  f32x4 sA[8], sB[8];
+  f32x4 fA[NT], fB[NT];
+#define AO_LEAD_LOAD1(ST, CH, Q)                                                                     \
+  {                                                                                                  \
+    int64_t i_ = (CH) * kLeadKC + scol;                                                              \
+    if (i_ > last4) i_ = last4;                                                                      \
+    unsigned mq_ = srow + 16 * (Q);                                                                  \
+    if (mq_ > mlast) mq_ = mlast;                                                                    \
+    unsigned ldo_ = (unsigned)a.ld;                                                                  \
+    asm volatile("" : "+s"(ldo_));                                                                   \
+    ST[Q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xblk + (uint64_t)mq_ * ldo_ + i_)); \
+  }
+#define AO_LEAD_LOAD(ST, CH) { _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) AO_LEAD_LOAD1(ST, CH, q_) }
+#define AO_LEAD_WRITE(ST, BUF)                                                                       \
+  {                                                                                                  \
+    float* base_ = lds + (BUF) * (kLeadRows * kLeadStride);                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                 \
+      *reinterpret_cast<f32x4*>(base_ + (srow + 16 * q_) * kLeadStride + scol) = ST[q_];             \
+  }
+  // B fragments of this wave's 16-i group, fetched one chunk ahead
+#define AO_LEAD_FRAG(FV, CH)                                                                         \
+  {                                                                                                  \
+    int64_t gg = (CH) * (kLeadKC / 16) + w;                                                          \
+    if (gg > Cg16) gg = Cg16;                                          /* ragged last chunk: the zero group */ \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) FV[nt] = fbase[nt * fnt + gg * 64];            \
+  }
+#define AO_LEAD_TILE(XV, TL, FV)                                                                     \
+  {                                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                    \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                              \
+        acc[nt][TL] = __builtin_amdgcn_mfma_f32_16x16x4f32(XV[t], FV[nt][t], acc[nt][TL], 0, 0, 0);  \
+  }
+  // consume this wave's 16 i of chunk CH from LDS buffer BUF; meanwhile fetch the next chunk's fragments
+  // (if NF) and refill register set ST with chunk CHN (if PF): one staging load per row tile
+#define AO_LEAD_COMPUTE(BUF, CH, FV, FVN, NF, ST, CHN, PF)                                           \
+  {                                                                                                  \
+    const float* xs_ = lds + (BUF) * (kLeadRows * kLeadStride) + r16 * kLeadStride + 16 * w + 4 * q4; \
+    if (NF) AO_LEAD_FRAG(FVN, (CH) + 1)                                                              \
+    _Pragma("unroll") for (int hb = 0; hb < 2; ++hb) {                                               \
+      f32x4 xv_[4];                                                                                  \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)           /* (macro arguments mention the caller's k) */ \
+        xv_[j_] = *reinterpret_cast<const f32x4*>(xs_ + 16 * (4 * hb + j_) * kLeadStride);           \
+      __builtin_amdgcn_sched_barrier(0);                                                             \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                             \
+        AO_LEAD_TILE(xv_[j_], 4 * hb + j_, FV)                                                       \
+        if (PF) AO_LEAD_LOAD1(ST, CHN, 4 * hb + j_)                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+      }                                                                                              \
+    }                                                                                                \
+  }
+  const int64_t n = c1 > c0 ? c1 - c0 : 0;
+  if (n > 0) {
+    AO_LEAD_LOAD(sA, c0)
+    AO_LEAD_FRAG(fA, c0)
+    AO_LEAD_WRITE(sA, 0)
+  }
+  if (n > 1) AO_LEAD_LOAD(sA, c0 + 1)
+  if (n > 2) AO_LEAD_LOAD(sB, c0 + 2)
+  __syncthreads();
+#pragma nounroll
+  for (int64_t k = 0; k < n; k += 2) {
+    if (k + 1 < n) AO_LEAD_WRITE(sA, 1)
+    if (k + 3 < n) AO_LEAD_COMPUTE(0, c0 + k, fA, fB, true, sA, c0 + k + 3, true)
+    else if (k + 1 < n) AO_LEAD_COMPUTE(0, c0 + k, fA, fB, true, sA, c0, false)
+    else AO_LEAD_COMPUTE(0, c0 + k, fA, fB, false, sA, c0, false)
+    __syncthreads();
+    if (k + 1 >= n) break;
+    if (k + 2 < n) AO_LEAD_WRITE(sB, 0)
+    if (k + 4 < n) AO_LEAD_COMPUTE(1, c0 + k + 1, fB, fA, true, sB, c0 + k + 4, true)
+    else if (k + 2 < n) AO_LEAD_COMPUTE(1, c0 + k + 1, fB, fA, true, sB, c0, false)
+    else AO_LEAD_COMPUTE(1, c0 + k + 1, fB, fA, false, sB, c0, false)
+    __syncthreads();
+  }
+#undef AO_LEAD_LOAD1
+#undef AO_LEAD_LOAD
+#undef AO_LEAD_WRITE
+#undef AO_LEAD_FRAG
+#undef AO_LEAD_TILE
+#undef AO_LEAD_COMPUTE
+  // sum the four waves' partial tiles through LDS, 16 columns per round, region w: [128][17];
+  // the 128 x R block of T is contiguous in memory and is written with flat coalesced stores
+  __syncthreads();
+  constexpr int kEpiStride = 17;
+  float* Tc = a.T + (int64_t)slice * a.M * a.R + m0 * a.R;
+  const int64_t rows_here = (a.M - m0 < kLeadRows) ? (a.M - m0) : kLeadRows;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float* reg = lds + w * (kLeadRows * kEpiStride);
+#pragma unroll
+    for (int tl = 0; tl < 8; ++tl)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) reg[(16 * tl + 4 * q4 + i) * kEpiStride + r16] = acc[nt][tl][i];
+    __syncthreads();
+    int ncol = a.R - 16 * nt;                        // columns of this round
+    if (ncol > 16) ncol = 16;
+    const int total = (int)rows_here * ncol;
+    for (int e = tid; e < total; e += 256) {
+      const int row = e / ncol, col = e - row * ncol;
+      const float* p = lds + row * kEpiStride + col;
+      const float v = (p[0] + p[kLeadRows * kEpiStride]) + (p[2 * kLeadRows * kEpiStride] + p[3 * kLeadRows * kEpiStride]);
+      Tc[(int64_t)row * a.R + 16 * nt + col] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // f64 contraction (parity mode)
 // ---------------------------------------------------------------------------
 template <int NT>
@@ -681,7 +838,7 @@ static int nt_of(int R, int prec) {
 size_t ContractPlan::frag_bytes(int prec) const {
   const int64_t Cg = cdiv(C, kGroup);
   // f32: the 32-column layout needs nt32*1024 B per group, the 16-column layout nt16*512 + 128 (extras)
-  return (size_t)(nt_of(R, prec) * 1024 + 1152) * Cg;
+  return (size_t)(nt_of(R, prec) * 1024 + 1152) * Cg + 8192;
 }
 
 ContractPlan make_plan(int64_t nbatch, int64_t batch_stride, int64_t M, int64_t ld, int64_t C, int R,
@@ -722,9 +879,6 @@ static void launch_contract_lead(const void* X, const ContractPlan& pl, const do
   const int64_t Cg = cdiv(pl.C, kGroup);
   const int NT = nt_of(pl.R, AOADMM_PREC_F32);
   AO_REQUIRE(pl.ld % 4 == 0 && pl.ld >= 4, "f32 layout must be padded to 4");
-  const int64_t total = (int64_t)NT * Cg * 256;
-  pack_frag_lead_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (float*)frag_ws);
-  AO_KERNEL_CHECK();
   LArgs a;
   a.X = (const float*)X; a.frag = (const float*)frag_ws; a.T = (float*)T;
   a.M = pl.M; a.ld = pl.ld; a.C = pl.C; a.Cg = Cg; a.R = pl.R;
@@ -733,6 +887,33 @@ static void launch_contract_lead(const void* X, const ContractPlan& pl, const do
   AO_REQUIRE(nblk < (int64_t)2147483647, "tensor too large for one launch");
   dim3 grid((unsigned)nblk, (unsigned)pl.nchunk);
   const size_t sh = (size_t)2 * kLeadRows * kLeadStride * sizeof(float);
+  static const bool use32 = getenv("AOADMM_CONTRACT_32") != nullptr;     // development switch: 32x32x2 kernels
+  if (!use32) {
+    const int nt16 = (pl.R + 15) / 16;
+    const int64_t Cg16 = cdiv(pl.C, 16) + 1;           // + one all-zero group: the ragged last chunk multiplies by it
+    const int64_t total = (int64_t)nt16 * Cg16 * 256;
+    pack_frag_lead16_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, nt16, Cg16, (float*)frag_ws);
+    AO_KERNEL_CHECK();
+    static bool attr16 = false;
+    if (!attr16) {
+#define AO_SET(K) AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+      AO_SET(contract_lead16_f32<1>) AO_SET(contract_lead16_f32<2>) AO_SET(contract_lead16_f32<3>) AO_SET(contract_lead16_f32<4>)
+#undef AO_SET
+      attr16 = true;
+    }
+    if (ev0) AO_HIP(hipEventRecord(ev0, s));
+    if (nt16 == 1) contract_lead16_f32<1><<<grid, 256, sh, s>>>(a);
+    else if (nt16 == 2) contract_lead16_f32<2><<<grid, 256, sh, s>>>(a);
+    else if (nt16 == 3) contract_lead16_f32<3><<<grid, 256, sh, s>>>(a);
+    else if (nt16 == 4) contract_lead16_f32<4><<<grid, 256, sh, s>>>(a);
+    else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
+    if (ev1) AO_HIP(hipEventRecord(ev1, s));
+    AO_KERNEL_CHECK();
+    return;
+  }
+  const int64_t total = (int64_t)NT * Cg * 256;
+  pack_frag_lead_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (float*)frag_ws);
+  AO_KERNEL_CHECK();
   static bool attr = false;
   if (!attr) {
     AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_lead_f32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
