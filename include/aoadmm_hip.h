@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AOADMM_ABI_VERSION 1
+#define AOADMM_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------ */
 enum {
@@ -124,6 +124,9 @@ typedef struct aoadmm_result {
   int32_t exit_abs[4];          /* per quantity: 1 = 'AbsFuncTol', 0 = 'RelFuncTol' */
   double *func_val_conv, *func_coupl_conv, *func_constr_conv, *func_PAR2_coupl, *time_at_it;
   double *innerIters;
+  /* EM missing data (cmtf_fun_AOADMM.m:408-441, :485, :490-492): NaN / untouched without Z.miss */
+  double f_rel_missing;
+  double *func_rel_missing;     /* MaxOuterIters+1 entries, [0] = NaN; may be NULL */
 } aoadmm_result;
 
 /* ---- library / context ------------------------------------------------- */
@@ -168,6 +171,12 @@ int aoadmm_tensor_upload(aoadmm_ctx* ctx, int p, const double* data, int precisi
 int aoadmm_tensor_upload_rows(aoadmm_ctx* ctx, int p, const double* block, int64_t row_offset,
                               int64_t local_rows, int precision);
 int aoadmm_par2_slab_upload(aoadmm_ctx* ctx, int p, int k, const double* Xk);
+/* Z.miss{p} (cmtf_AOADMM.m:68-121): one byte per entry, 1 = observed, 0 = missing, same shape and
+ * column-major order as Z.object{p} (the FULL array also when row-sharded) / as slab k.  Upload after the
+ * data.  A block with a mask is handled by EM imputation inside aoadmm_solve (cmtf_fun_AOADMM.m:408-441):
+ * the resident copy of the data is overwritten at the missing positions every outer iteration. */
+int aoadmm_tensor_mask_upload(aoadmm_ctx* ctx, int p, const uint8_t* mask);
+int aoadmm_par2_slab_mask_upload(aoadmm_ctx* ctx, int p, int k, const uint8_t* mask_k);
 /* device-side synthetic CP tensor: X = [[A1,..,AN]] + noise, ||X|| = 1;
  * never crosses PCIe.  normsq_out receives ||X||^2 after normalisation. */
 int aoadmm_tensor_synth(aoadmm_ctx* ctx, int p, int rank, uint64_t seed, double noise, int precision);

@@ -26,7 +26,7 @@ SYMBOLS = [
     'aoadmm_model_begin', 'aoadmm_model_set_mode', 'aoadmm_model_set_mode_slabs', 'aoadmm_model_add_cp',
     'aoadmm_model_add_par2', 'aoadmm_model_set_constraint', 'aoadmm_model_set_coupling',
     'aoadmm_model_set_coupling_type', 'aoadmm_model_set_ridge', 'aoadmm_model_end', 'aoadmm_tensor_upload',
-    'aoadmm_tensor_upload_rows', 'aoadmm_par2_slab_upload', 'aoadmm_tensor_synth', 'aoadmm_tensor_normsq',
+    'aoadmm_tensor_upload_rows', 'aoadmm_par2_slab_upload', 'aoadmm_tensor_mask_upload', 'aoadmm_par2_slab_mask_upload', 'aoadmm_tensor_synth', 'aoadmm_tensor_normsq',
     'aoadmm_state_set', 'aoadmm_state_get', 'aoadmm_solve', 'aoadmm_resident_mttkrp', 'aoadmm_kernel_stats',
     'aoadmm_op_mttkrp', 'aoadmm_op_gram', 'aoadmm_op_chol', 'aoadmm_op_prox', 'aoadmm_op_admm_constrained',
 ]
@@ -66,6 +66,7 @@ class Result(C.Structure):
         ('func_val_conv', C.POINTER(C.c_double)), ('func_coupl_conv', C.POINTER(C.c_double)),
         ('func_constr_conv', C.POINTER(C.c_double)), ('func_PAR2_coupl', C.POINTER(C.c_double)),
         ('time_at_it', C.POINTER(C.c_double)), ('innerIters', C.POINTER(C.c_double)),
+        ('f_rel_missing', C.c_double), ('func_rel_missing', C.POINTER(C.c_double)),
     ]
 
 
@@ -106,6 +107,8 @@ def load_library():
     lib.aoadmm_tensor_upload.argtypes = [vp, C.c_int, dp, C.c_int]
     lib.aoadmm_tensor_upload_rows.argtypes = [vp, C.c_int, dp, i64, i64, C.c_int]
     lib.aoadmm_par2_slab_upload.argtypes = [vp, C.c_int, C.c_int, dp]
+    lib.aoadmm_tensor_mask_upload.argtypes = [vp, C.c_int, C.POINTER(C.c_uint8)]
+    lib.aoadmm_par2_slab_mask_upload.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
     lib.aoadmm_tensor_synth.argtypes = [vp, C.c_int, C.c_int, C.c_uint64, C.c_double, C.c_int]
     lib.aoadmm_tensor_normsq.argtypes = [vp, C.c_int, dp]
     lib.aoadmm_state_set.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, i64, i64]

@@ -182,6 +182,14 @@ int aoadmm_tensor_synth(aoadmm_ctx* ctx, int p, int rank, uint64_t seed, double 
   CTX_OR_FAIL(ctx);
   return guarded([&] { ctx->eng->tensor_synth(p, rank, seed, noise, precision); });
 }
+int aoadmm_tensor_mask_upload(aoadmm_ctx* ctx, int p, const uint8_t* mask) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->tensor_mask_upload(p, mask); });
+}
+int aoadmm_par2_slab_mask_upload(aoadmm_ctx* ctx, int p, int k, const uint8_t* mask_k) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->par2_slab_mask_upload(p, k, mask_k); });
+}
 int aoadmm_tensor_normsq(aoadmm_ctx* ctx, int p, double* out) {
   CTX_OR_FAIL(ctx);
   return guarded([&] {

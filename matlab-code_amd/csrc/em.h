@@ -1,0 +1,36 @@
+// EM missing-data imputation (functions/cmtf_fun_AOADMM.m:408-441) and the masked objective
+// (:1224-1226, :1249-1252) as one pass over a data block:
+//   for every entry   m = model value from the current factors
+//   observed  (mask 1): obs_res += (x - m)^2 ; obs_x2 += x^2
+//   missing   (mask 0): num += (m - x)^2 ; den += x^2 ; x <- m   (update mode only)
+// out4 = {num, den, obs_res, obs_x2}, fixed summation order.
+#pragma once
+#include "common.h"
+
+namespace aoadmm {
+
+struct EmCpArgs {
+  void* X;                 // float / double, first dimension padded to `Ipad`
+  const uint8_t* mask;     // same layout, 1 = observed
+  const double *A, *B, *C; // factors, column-major; A points at the block's first local row; C null for matrices
+  int64_t ldA, ldB, ldC;
+  int64_t I, Ipad, J, K;   // local rows, padded rows, second mode, third mode (1 for matrices)
+  int R;
+  int update;              // 0: statistics only, 1: also overwrite the missing entries
+};
+size_t em_cp_ws_bytes(int64_t Ipad, int64_t K);
+// ws: em_cp_ws_bytes ; out4: device, 4 doubles
+void em_cp_pass(const EmCpArgs& a, int prec, double* ws, double* out4, hipStream_t s);
+
+struct EmPar2Args {
+  double* X;               // slabs back to back (I x J_k each), fp64
+  const uint8_t* mask;     // same layout
+  const double *A, *B, *C; // A: I x R ; B: slabs J_k x R back to back ; C: K x R (ldC = K)
+  const int64_t* off;      // device, K+1
+  int K, I, R;
+  int update;
+};
+// ws: 4*K doubles
+void em_par2_pass(const EmPar2Args& a, double* ws, double* out4, hipStream_t s);
+
+}  // namespace aoadmm

@@ -37,6 +37,9 @@ struct CpBlock {
   uint64_t cached_version = 0;
   ContractPlan plan;
   DevBuf T, frag, scratch, ft, tmpA, tmpB;
+  // Z.miss{p}: one byte per entry in the layout of X (and of Xt for matrices), 1 = observed
+  DevBuf mask, maskT;
+  bool has_mask = false;
 };
 
 struct ModeInfo {
@@ -70,6 +73,8 @@ struct Par2Block {
   int64_t Jtot = 0;
   int Jmax = 0;
   DevBuf X;                       // slabs back to back, fp64
+  DevBuf mask;                    // Z.miss{p}{k}: one byte per entry, same layout, 1 = observed
+  bool has_mask = false;
   std::vector<char> have_slab;
   DevBuf DeltaB, DeltaBold, P, Pold, muDB;        // state (G.DeltaB, G.P, G.mu_DeltaB)
   bool has_DeltaB = false;
@@ -131,6 +136,8 @@ class Engine {
   void tensor_upload(int p, const double* data, int prec, int64_t row0, int64_t local_rows);
   void tensor_synth(int p, int rank, uint64_t seed, double noise, int prec);
   void par2_slab_upload(int p, int k, const double* Xk);
+  void tensor_mask_upload(int p, const uint8_t* mask);
+  void par2_slab_mask_upload(int p, int k, const uint8_t* mask);
   double tensor_normsq(int p);
 
   // state
@@ -169,6 +176,9 @@ class Engine {
   void prepare_mode_system(int m, int nrho, const aoadmm_options& opt);
   void coupled_admm(int c, const aoadmm_options& opt);
   void eval_objective_enqueue(bool first);
+  bool has_missing() const;
+  void em_pass_enqueue(int p, int update);         // statistics of tensor p into its EM slots (+ imputation)
+  double* em_slot(int p) const;
   void ensure_mode_work(ModeInfo& mi);
   // PARAFAC2 (solver_par2.hip)
   void par2_ensure_work(TensorInfo& t);
@@ -190,6 +200,7 @@ class Engine {
   DevBuf ctls_;          // AdmmCtl[n_modes + n_couplings]
   DevBuf slots_;         // objective scalars
   DevBuf redws_;         // reduction workspace
+  DevBuf emws_;          // EM pass partial sums
   DevBuf atbws_;
   DevBuf staging_;
   KernelStats kstats_[2];   // [0] streaming contraction, [1] leading-mode contraction

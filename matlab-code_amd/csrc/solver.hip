@@ -2,6 +2,7 @@
 // functions/cmtf_fun_AOADMM.m:87-476 (outer loop), :625-695 / :904-983 (coupled ADMM
 // cases 0 and 4), :1213-1363 (objective), functions/evaluate_stopping_conditions.m.
 #include "solver.h"
+#include "em.h"
 
 #include <rccl/rccl.h>
 
@@ -225,7 +226,7 @@ void Engine::model_end() {
   }
   ctls_.alloc((size_t)(n_modes_ + n_couplings_ + 1) * sizeof(AdmmCtl));
   AO_HIP(hipMemsetAsync(ctls_.p, 0, ctls_.bytes, stream_));
-  slots_.alloc((size_t)(n_modes_ * (kSlotsPerMode + kResidPerMode) + 2 * n_tensors_ + 16) * sizeof(double));
+  slots_.alloc((size_t)(n_modes_ * (kSlotsPerMode + kResidPerMode) + 2 * n_tensors_ + 16 + 4 * n_tensors_) * sizeof(double));
   AO_HIP(hipMemsetAsync(slots_.p, 0, slots_.bytes, stream_));
   AO_HIP(hipStreamSynchronize(stream_));
   model_done_ = true;
@@ -317,6 +318,17 @@ double Engine::tensor_normsq(int p) {
     DevBuf ws;
     ws.alloc(1024 * sizeof(double) + 64);
     double* slot = slots_.d() + n_modes_ * (kSlotsPerMode + kResidPerMode) + 2 * n_tensors_;
+    if (t.par2 ? t.p2.has_mask : t.blk.has_mask) {
+      // ||miss .* X||^2 (cmtf_AOADMM.m:133-148): the observed-entry sum of squares of a statistics-only EM pass
+      // (needs factors on the device: solve() calls this after the state checks)
+      em_pass_enqueue(p, 0);
+      double h4[4];
+      AO_HIP(hipMemcpyAsync(h4, em_slot(p), sizeof h4, hipMemcpyDeviceToHost, stream_));
+      AO_HIP(hipStreamSynchronize(stream_));
+      t.normsq = h4[3];
+      t.normsq_valid = true;
+      return t.normsq;
+    }
     if (t.par2) {   // sum_k ||X_k||_F^2  (cmtf_AOADMM.m:145-155)
       tensor_sumsq(slot, t.p2.X.p, AOADMM_PREC_F64, (int64_t)t.p2.I * t.p2.Jtot, ws.d(), stream_);
     } else {
@@ -371,6 +383,94 @@ void Engine::tensor_synth(int p, int rank, uint64_t seed, double noise, int prec
   b.has_data = true;
   b.cached_mode = -1;
   t.normsq_valid = false;
+}
+
+// ---------------------------------------------------------------------------
+// missing data (Z.miss, cmtf_AOADMM.m:68-121)
+// ---------------------------------------------------------------------------
+void Engine::tensor_mask_upload(int p, const uint8_t* mask) {
+  AO_REQUIRE(p >= 0 && p < n_tensors_ && !tensors_[p].par2, "tensor %d is not a CP block", p);
+  AO_REQUIRE(mask != nullptr, "null mask");
+  TensorInfo& t = tensors_[p];
+  CpBlock& b = t.blk;
+  AO_REQUIRE(b.has_data, "upload Z.object{%d} before Z.miss{%d}", p + 1, p + 1);
+  AO_REQUIRE(b.nd == 2 || b.nd == 3, "Z.miss is supported for matrices and 3-way tensors on the device");
+  AO_HIP(hipSetDevice(device_));
+  const int64_t Iloc = b.dims[0], Ip = b.X.pad0, Ifull = b.full0;
+  int64_t ncols = 1;
+  for (int i = 1; i < b.nd; ++i) ncols *= b.dims[i];
+  b.mask.alloc((size_t)Ip * ncols);
+  AO_HIP(hipMemsetAsync(b.mask.p, 1, (size_t)Ip * ncols, stream_));
+  // rows [row0, row0 + Iloc) of every column of the full column-major mask; the padding rows stay 1
+  AO_HIP(hipMemcpy2DAsync(b.mask.p, (size_t)Ip, mask + b.row0, (size_t)Ifull, (size_t)Iloc, (size_t)ncols,
+                          hipMemcpyHostToDevice, stream_));
+  if (b.nd == 2) {                                   // matrices keep a transposed copy of the data: mask too
+    const int64_t J = b.dims[1], Jp = b.Xt.pad0;
+    std::vector<uint8_t> mt((size_t)Jp * Iloc, 1);
+    for (int64_t i = 0; i < Iloc; ++i)
+      for (int64_t j = 0; j < J; ++j) mt[(size_t)j + (size_t)Jp * i] = mask[b.row0 + i + Ifull * j];
+    b.maskT.alloc(mt.size());
+    AO_HIP(hipMemcpyAsync(b.maskT.p, mt.data(), mt.size(), hipMemcpyHostToDevice, stream_));
+    AO_HIP(hipStreamSynchronize(stream_));
+  }
+  AO_HIP(hipStreamSynchronize(stream_));
+  b.has_mask = true;
+  t.normsq_valid = false;
+}
+
+bool Engine::has_missing() const {
+  for (int p = 0; p < n_tensors_; ++p)
+    if (tensors_[p].par2 ? tensors_[p].p2.has_mask : tensors_[p].blk.has_mask) return true;
+  return false;
+}
+
+double* Engine::em_slot(int p) const {
+  return slots_.d() + n_modes_ * (kSlotsPerMode + kResidPerMode) + 2 * n_tensors_ + 16 + 4 * p;
+}
+
+// One EM pass over tensor p with the current factors: {num, den, obs_res, obs_x2} -> em_slot(p), all-reduced
+// over the row shards; update = 1 also overwrites the missing entries with the model (:416-435).
+void Engine::em_pass_enqueue(int p, int update) {
+  TensorInfo& t = tensors_[p];
+  if (t.par2) {
+    Par2Block& b = t.p2;
+    EmPar2Args a;
+    a.X = b.X.d(); a.mask = b.mask.as<uint8_t>();
+    a.A = modes_[t.modes[0]].fac.d(); a.B = modes_[t.modes[1]].fac.d(); a.C = modes_[t.modes[2]].fac.d();
+    a.off = b.off_d.as<int64_t>(); a.K = b.K; a.I = b.I; a.R = b.R; a.update = update;
+    emws_.ensure((size_t)b.K * 4 * sizeof(double));
+    em_par2_pass(a, emws_.d(), em_slot(p), stream_);
+    return;
+  }
+  CpBlock& b = t.blk;
+  const ModeInfo& m0 = modes_[t.modes[0]];
+  const ModeInfo& m1 = modes_[t.modes[1]];
+  EmCpArgs a;
+  a.X = b.X.data.p; a.mask = b.mask.as<uint8_t>();
+  a.A = m0.fac.d() + (comm_ ? b.row0 : 0); a.ldA = m0.rows;
+  a.B = m1.fac.d(); a.ldB = m1.rows;
+  a.C = nullptr; a.ldC = 0;
+  a.I = b.dims[0]; a.Ipad = b.X.pad0; a.J = b.dims[1]; a.K = 1; a.R = m0.R; a.update = update;
+  if (b.nd == 3) {
+    const ModeInfo& m2 = modes_[t.modes[2]];
+    a.C = m2.fac.d(); a.ldC = m2.rows; a.K = b.dims[2];
+  }
+  emws_.ensure(em_cp_ws_bytes(a.Ipad, a.K));
+  em_cp_pass(a, b.X.prec, emws_.d(), em_slot(p), stream_);
+  if (b.nd == 2 && update) {
+    // same imputation on the transposed copy (roles of the two factors swapped); its statistics are discarded
+    EmCpArgs at = a;
+    at.X = b.Xt.data.p; at.mask = b.maskT.as<uint8_t>();
+    at.A = m1.fac.d(); at.ldA = m1.rows; at.B = m0.fac.d() + (comm_ ? b.row0 : 0); at.ldB = m0.rows;
+    at.I = b.dims[1]; at.Ipad = b.Xt.pad0; at.J = b.dims[0];
+    emws_.ensure(em_cp_ws_bytes(at.Ipad, 1) + 64);
+    DevBuf scratch4;
+    scratch4.alloc(4 * sizeof(double));
+    em_cp_pass(at, b.Xt.prec, emws_.d(), scratch4.d(), stream_);
+    AO_HIP(hipStreamSynchronize(stream_));
+  }
+  allreduce(em_slot(p), 4);
+  if (update) b.cached_mode = -1;                    // the data changed: cached partial contractions are stale
 }
 
 // ---------------------------------------------------------------------------
@@ -910,9 +1010,12 @@ void Engine::eval_objective_enqueue(bool first) {
   };
   for (int p = 0; p < n_tensors_; ++p) {
     TensorInfo& t = tensors_[p];
+    const bool masked = t.par2 ? t.p2.has_mask : t.blk.has_mask;
+    if (masked && first) em_pass_enqueue(p, 0);  // observed-entry residual (:1224-1226, :1249-1252); later
+                                                 // evaluations reuse the statistics of the EM update pass
     if (t.par2) {
       par2_objective_enqueue(t);                 // direct residual (:1262-1264) + internal-coupling gaps (:1355)
-      if (!first && t.last_pos == 0) {           // shortcut through last_mttkrp / last_had (:1254-1260)
+      if (!masked && !first && t.last_pos == 0) {           // shortcut through last_mttkrp / last_had (:1254-1260)
         ModeInfo& lm = modes_[t.modes[0]];
         double* sp = S + n_modes_ * kSlotsPerMode + 2 * p;
         add(RT_DOT, sp + 0, lm.A.d(), lm.fac.d(), lm.rows * lm.R);
@@ -920,6 +1023,7 @@ void Engine::eval_objective_enqueue(bool first) {
       }
       continue;
     }
+    if (masked) continue;
     if (first) {
       // cp_func.m:47-55 / pca_func.m:29-39: same formula with the first mode's MTTKRP
       ModeInfo& m0 = modes_[t.modes[0]];
@@ -987,7 +1091,6 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   for (int p = 0; p < n_tensors_; ++p) {
     AO_REQUIRE(tensors_[p].blk.has_data, "tensor %d has no data (Z.object{%d})", p, p + 1);
     AO_REQUIRE(tensors_[p].nmodes <= 3, "tensors of order > 3 are not in the device path yet");
-    (void)tensor_normsq(p);
   }
   for (int m = 0; m < n_modes_; ++m) {
     ModeInfo& mi = modes_[m];
@@ -1000,6 +1103,15 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     ensure_mode_work(mi);
     if (!mi.slabs) compute_gram(mi);                                         // :62-81
   }
+  for (int p = 0; p < n_tensors_; ++p) {
+    TensorInfo& t = tensors_[p];
+    if (t.par2) {
+      for (int k = 0; k < t.p2.K; ++k)
+        AO_REQUIRE(t.p2.have_P[k] && t.p2.have_mu[k], "G.P{%d}{%d} / G.mu_DeltaB{%d}{%d} missing", p + 1, k + 1, p + 1, k + 1);
+    }
+    (void)tensor_normsq(p);          // Znorm_const{p}; a masked block needs the factors (statistics-only EM pass)
+  }
+  const bool has_miss = has_missing();
   for (int p = 0; p < n_tensors_; ++p) {
     TensorInfo& t = tensors_[p];
     if (!t.par2) continue;
@@ -1018,15 +1130,17 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     void* p = nullptr; hipEvent_t ev = nullptr;
     ~Pinned() { if (p) (void)hipHostFree(p); if (ev) (void)hipEventDestroy(ev); }
   } pin;
-  AO_HIP(hipHostMalloc(&pin.p, nslots * sizeof(double) + nctl * sizeof(AdmmCtl), hipHostMallocDefault));
+  AO_HIP(hipHostMalloc(&pin.p, (nslots + 4 * n_tensors_) * sizeof(double) + nctl * sizeof(AdmmCtl), hipHostMallocDefault));
   AO_HIP(hipEventCreateWithFlags(&pin.ev, hipEventDisableTiming));
   double* hs = static_cast<double*>(pin.p);
-  AdmmCtl* hctl = reinterpret_cast<AdmmCtl*>(hs + nslots);
+  double* hem = hs + nslots;                                                   // EM statistics, 4 per tensor
+  AdmmCtl* hctl = reinterpret_cast<AdmmCtl*>(hem + 4 * n_tensors_);
 
   bool eval_first = true;
   auto enqueue_readback = [&]() {
     AO_HIP(hipMemcpyAsync(hs, slots_.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream_));
     AO_HIP(hipMemcpyAsync(hctl, ctls_.p, nctl * sizeof(AdmmCtl), hipMemcpyDeviceToHost, stream_));
+    if (has_miss) AO_HIP(hipMemcpyAsync(hem, em_slot(0), 4 * n_tensors_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     AO_HIP(hipEventRecord(pin.ev, stream_));
   };
   auto finish_eval = [&](double f[4]) {
@@ -1039,6 +1153,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     for (int p = 0; p < n_tensors_; ++p) {
       TensorInfo& t = tensors_[p];
       const double* sp = hs + n_modes_ * kSlotsPerMode + 2 * p;
+      const bool masked = t.par2 ? t.p2.has_mask : t.blk.has_mask;
       if (t.par2) {
         Par2Block& b = t.p2;
         std::vector<double> res(b.K), q((size_t)b.K * 4);
@@ -1046,7 +1161,8 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
         AO_HIP(hipMemcpyAsync(q.data(), b.q.p, (size_t)b.K * 4 * sizeof(double), hipMemcpyDeviceToHost, stream_));
         AO_HIP(hipStreamSynchronize(stream_));
         double fp = 0.0;
-        if (!eval_first && t.last_pos == 0) fp = t.normsq - 2.0 * (sp[0] / t.weight) + sp[1];   // :1254-1260
+        if (masked) fp = hem[4 * p + 2];                                                        // :1249-1252
+        else if (!eval_first && t.last_pos == 0) fp = t.normsq - 2.0 * (sp[0] / t.weight) + sp[1];   // :1254-1260
         else for (int k = 0; k < b.K; ++k) fp += res[k];                                        // :1262-1264
         ft += t.weight * fp;                                                                    // :1267
         const ModeInfo& mB = modes_[t.modes[1]];
@@ -1069,6 +1185,8 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
           if (g != 0.0) ++ncon;
           if (has_ridge_) ft += mB.ridge * nb2;                                                 // :1292-1295 (quirk: only if constrained)
         }
+      } else if (masked) {
+        ft += t.weight * hem[4 * p + 2];                                       // :1224-1226 = w * ||miss.*(X - M)||^2
       } else {
         const double f2 = sp[0] / t.weight;                                   // last_mttkrp = A*1/w (:121)
         ft += t.weight * (t.normsq - 2.0 * f2 + sp[1]);                        // :1235-1241
@@ -1113,6 +1231,8 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   if (out->func_constr_conv) out->func_constr_conv[0] = f[2];
   if (out->func_PAR2_coupl) out->func_PAR2_coupl[0] = f[3];
   if (out->time_at_it) out->time_at_it[0] = 0.0;
+  double f_rel_missing = std::nan("");                                          // :30
+  if (out->func_rel_missing) out->func_rel_missing[0] = f_rel_missing;
   const auto t0 = std::chrono::steady_clock::now();
 
   int iter = 1;
@@ -1139,6 +1259,9 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
         for (int m : cm) { compute_gram(modes_[m]); modes_[m].version++; }      // :393-403
       }
     }
+    if (has_miss)                                                              // EM imputation (:408-441)
+      for (int p = 0; p < n_tensors_; ++p)
+        if (tensors_[p].par2 ? tensors_[p].p2.has_mask : tensors_[p].blk.has_mask) em_pass_enqueue(p, 1);
     for (int i = 0; i < 4; ++i) fo[i] = f[i];
     eval_objective_enqueue(false);                                             // :447
     enqueue_readback();
@@ -1163,9 +1286,18 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     }
     stop = stop_one(f[0], fo[0], opt) && stop_one(f[1], fo[1], opt) && stop_one(f[2], fo[2], opt) &&
            stop_one(f[3], fo[3], opt);                                         // :456
+    if (has_miss) {
+      double num = 0.0, den = 0.0;
+      for (int p = 0; p < n_tensors_; ++p)
+        if (tensors_[p].par2 ? tensors_[p].p2.has_mask : tensors_[p].blk.has_mask) { num += hem[4 * p]; den += hem[4 * p + 1]; }
+      f_rel_missing = den > 0 ? std::sqrt(num / den) : std::sqrt(num);        // :436-440
+      if (out->func_rel_missing) out->func_rel_missing[iter] = f_rel_missing;
+      stop = stop && (f_rel_missing < opt.OuterRelTol);                        // :457-459
+    }
     ++iter;
   }
   out->f_tensors = f[0]; out->f_couplings = f[1]; out->f_constraints = f[2]; out->f_PAR2_couplings = f[3];
+  out->f_rel_missing = f_rel_missing;
   out->OuterIterations = iter - 1;
   out->exit_code = iter > opt.MaxOuterIters ? 0 : 1;                           // make_exit_flag.m:4-5
   for (int i = 0; i < 4; ++i) out->exit_abs[i] = f[i] < opt.AbsFuncTol ? 1 : 0;

@@ -67,6 +67,24 @@ void Engine::par2_slab_upload(int p, int k, const double* Xk) {
   tensors_[p].normsq_valid = false;
 }
 
+void Engine::par2_slab_mask_upload(int p, int k, const uint8_t* mask) {
+  AO_REQUIRE(model_done_, "call aoadmm_model_end first");
+  AO_REQUIRE(p >= 0 && p < n_tensors_ && tensors_[p].par2, "tensor %d is not a PARAFAC2 block", p);
+  AO_REQUIRE(mask != nullptr, "null mask");
+  AO_HIP(hipSetDevice(device_));
+  Par2Block& b = tensors_[p].p2;
+  AO_REQUIRE(k >= 0 && k < b.K, "slab %d out of range", k);
+  if (!b.has_mask) {
+    b.mask.alloc((size_t)b.I * b.Jtot);
+    AO_HIP(hipMemsetAsync(b.mask.p, 1, (size_t)b.I * b.Jtot, stream_));     // slabs without a mask: fully observed
+    b.has_mask = true;
+  }
+  const int64_t Jk = b.off_h[k + 1] - b.off_h[k];
+  AO_HIP(hipMemcpyAsync(b.mask.as<uint8_t>() + (int64_t)b.I * b.off_h[k], mask, (size_t)b.I * Jk, hipMemcpyHostToDevice, stream_));
+  AO_HIP(hipStreamSynchronize(stream_));
+  tensors_[p].normsq_valid = false;
+}
+
 void Engine::par2_ensure_work(TensorInfo& t) {
   Par2Block& b = t.p2;
   const size_t RR = (size_t)b.R * b.R * sizeof(double);

@@ -201,8 +201,7 @@ def build_model(eng, Z, precision='f64'):
         if Z['loss_function'][p] != 'Frobenius':
             raise capi.UnsupportedOnDevice(capi.ERR_UNSUPPORTED,
                                            "loss '%s' needs the L-BFGS-B path of the MATLAB code" % Z['loss_function'][p])
-    if Z.get('miss') is not None and any(m is not None for m in Z['miss']):
-        raise capi.UnsupportedOnDevice(capi.ERR_UNSUPPORTED, 'Z.miss (EM imputation) stays on the MATLAB path')
+    miss = Z.get('miss') if Z.get('miss') is not None else [None] * P
     capi.check(lib.aoadmm_model_begin(eng.h, nb_modes, P, nb_couplings))
     R_of = {}
     for p in range(P):
@@ -264,10 +263,30 @@ def build_model(eng, Z, precision='f64'):
                 if tuple(X.shape) != tuple(int(Z['size'][m]) for m in md):
                     raise ValueError('Z.object{%d} has size %s, Z.size says %s' % (p + 1, X.shape, [Z['size'][m] for m in md]))
                 capi.check(lib.aoadmm_tensor_upload(eng.h, p, capi.dptr(X), prec))
+            if miss[p] is not None:                                                  # cmtf_AOADMM.m:78-97
+                if isinstance(obj, dict):
+                    raise ValueError('Z.miss needs explicit data in Z.object{%d}' % (p + 1))
+                mk = np.asarray(miss[p])
+                if tuple(mk.shape) != tuple(X.shape):
+                    raise ValueError('Z.miss{%d} size does not match Z.object{%d}.' % (p + 1, p + 1))
+                mk = np.asfortranarray(mk != 0, dtype=np.uint8)
+                capi.check(lib.aoadmm_tensor_mask_upload(eng.h, p, mk.ctypes.data_as(C.POINTER(C.c_uint8))))
         else:
             for k, Xk in enumerate(Z['object'][p]):
                 Xk = capi.as_f(Xk)
                 capi.check(lib.aoadmm_par2_slab_upload(eng.h, p, k, capi.dptr(Xk)))
+            if miss[p] is not None:                                                  # :98-120
+                K = len(Z['object'][p])
+                if not isinstance(miss[p], (list, tuple)) or len(miss[p]) != K:
+                    raise ValueError('Z.miss{%d} must be a cell array of length %d for PAR2.' % (p + 1, K))
+                for k in range(K):
+                    mk = np.asarray(miss[p][k])
+                    if not np.all((mk == 0) | (mk == 1)):
+                        raise ValueError('Z.miss{%d}{%d} must be a logical or binary (0/1) array.' % (p + 1, k + 1))
+                    if tuple(mk.shape) != tuple(np.asarray(Z['object'][p][k]).shape):
+                        raise ValueError('Z.miss{%d}{%d} size does not match Z.object{%d}{%d}.' % (p + 1, k + 1, p + 1, k + 1))
+                    mk = np.asfortranarray(mk != 0, dtype=np.uint8)
+                    capi.check(lib.aoadmm_par2_slab_mask_upload(eng.h, p, k, mk.ctypes.data_as(C.POINTER(C.c_uint8))))
 
 
 def _put(eng, field, index, slab, a):
@@ -344,26 +363,30 @@ def download_state(eng, Z, G):
     return out
 
 
-def run_solver(eng, alg_options, nb_modes):
+def run_solver(eng, alg_options, nb_modes, has_missing=False):
     """`[Fac,out] = cmtf_fun_AOADMM(...)` (cmtf_AOADMM.m:193) -> the `out` struct (cmtf_fun_AOADMM.m:480-494)."""
     o = _make_options(alg_options)
     n = int(o.MaxOuterIters) + 1
     bufs = {k: np.zeros(n) for k in ('func_val_conv', 'func_coupl_conv', 'func_constr_conv', 'func_PAR2_coupl', 'time_at_it')}
     inner = np.zeros((nb_modes, max(int(o.MaxOuterIters), 1)), order='F')
+    frm = np.full(n, np.nan)
     res = capi.Result()
     for k, b in bufs.items():
         setattr(res, k, capi.dptr(b))
     res.innerIters = capi.dptr(inner)
+    res.func_rel_missing = capi.dptr(frm)
     capi.check(eng.lib.aoadmm_solve(eng.h, C.byref(o), C.byref(res)))
     it = int(res.OuterIterations)
     out = {
         'f_tensors': res.f_tensors, 'f_couplings': res.f_couplings, 'f_constraints': res.f_constraints,
-        'f_PAR2_couplings': res.f_PAR2_couplings, 'f_rel_missing': float('nan'),
+        'f_PAR2_couplings': res.f_PAR2_couplings, 'f_rel_missing': res.f_rel_missing,
         'OuterIterations': it,
         'innerIters': inner[:, :max(it, 1)].copy(),
     }
     for k, b in bufs.items():
         out[k] = b[:it + 1].copy()
+    if has_missing:
+        out['func_rel_missing'] = frm[:it + 1].copy()                          # cmtf_fun_AOADMM.m:490-492
     names = ['f_tensors', 'f_couplings', 'f_constraints', 'f_PAR2_couplings']
     if res.exit_code == 0:
         out['exit_flag'] = 'maxIterations'                                   # make_exit_flag.m:4-5
@@ -406,7 +429,8 @@ def cmtf_AOADMM(Z, alg_options=None, init='random', init_options=None, rng=None,
     Z['_ranks'] = ranks
     build_model(eng, Z, precision)
     upload_state(eng, Z, G)
-    out = run_solver(eng, alg_options, nb_modes)
+    out = run_solver(eng, alg_options, nb_modes,
+                     has_missing=Z.get('miss') is not None and any(m is not None for m in Z['miss']))
     Fac = download_state(eng, Z, G)
     Zhat = []
     for p in range(len(Z['object'])):                                                 # :197-206

@@ -162,8 +162,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   for (int p = 0; p < P; ++p)
     if (str(mxGetCell(field(Z, "loss_function"), p)) != "Frobenius")
       mexErrMsgIdAndTxt("cmtf:hip:unsupported", "non-Frobenius losses need the L-BFGS-B path of the MATLAB code");
-  if (const mxArray* miss = field(Z, "miss", false))
-    if (!mxIsEmpty(miss)) mexErrMsgIdAndTxt("cmtf:hip:unsupported", "Z.miss (EM imputation) stays on the MATLAB path");
+  const mxArray* miss = field(Z, "miss", false);        // cmtf_fun_AOADMM_hip.m passes dense uint8 masks (1 = observed)
+  bool has_missing = false;
 
   check(aoadmm_model_begin(g_ctx, n_modes, P, n_couplings));
   for (int m = 0; m < n_modes; ++m) {
@@ -222,6 +222,27 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     } else {
       check(aoadmm_tensor_upload(g_ctx, p, mxGetDoubles(dense_data(obj)), precision));
     }
+    // Z.miss{p} (cmtf_AOADMM.m:68-121): same shape as the data, uint8
+    const mxArray* mk = (miss && !mxIsEmpty(miss) && (mwSize)p < mxGetNumberOfElements(miss)) ? mxGetCell(miss, p) : nullptr;
+    if (mk && !mxIsEmpty(mk)) {
+      has_missing = true;
+      if (mxIsCell(obj)) {
+        if (!mxIsCell(mk) || mxGetNumberOfElements(mk) != mxGetNumberOfElements(obj))
+          mexErrMsgIdAndTxt("cmtf:missingData:PAR2maskNotCell", "Z.miss{%d} must be a cell array of length %d for PAR2.", p + 1,
+                            (int)mxGetNumberOfElements(obj));
+        for (mwSize k = 0; k < mxGetNumberOfElements(obj); ++k) {
+          const mxArray* mkk = mxGetCell(mk, k);
+          if (!mxIsUint8(mkk) || mxGetNumberOfElements(mkk) != mxGetNumberOfElements(mxGetCell(obj, k)))
+            mexErrMsgIdAndTxt("cmtf:missingData:PAR2maskSliceSizeMismatch", "Z.miss{%d}{%d} size does not match Z.object{%d}{%d}.",
+                              p + 1, (int)k + 1, p + 1, (int)k + 1);
+          check(aoadmm_par2_slab_mask_upload(g_ctx, p, (int)k, static_cast<const uint8_t*>(mxGetData(mkk))));
+        }
+      } else {
+        if (!mxIsUint8(mk) || mxGetNumberOfElements(mk) != mxGetNumberOfElements(dense_data(obj)))
+          mexErrMsgIdAndTxt("cmtf:missingData:maskSizeMismatch", "Z.miss{%d} size does not match Z.object{%d}.", p + 1, p + 1);
+        check(aoadmm_tensor_mask_upload(g_ctx, p, static_cast<const uint8_t*>(mxGetData(mk))));
+      }
+    }
   }
 
   // ---- state: the struct G (init_coupled_AOADMM_CMTF.m:41-45)
@@ -264,11 +285,12 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
 
   // ---- solve
   const int n = o.MaxOuterIters + 1;
-  std::vector<double> fv(n), fc(n), fz(n), fp(n), tt(n), inner((size_t)n_modes * (o.MaxOuterIters > 0 ? o.MaxOuterIters : 1));
+  std::vector<double> fv(n), fc(n), fz(n), fp(n), tt(n), frm(n), inner((size_t)n_modes * (o.MaxOuterIters > 0 ? o.MaxOuterIters : 1));
   aoadmm_result res;
   std::memset(&res, 0, sizeof res);
   res.func_val_conv = fv.data(); res.func_coupl_conv = fc.data(); res.func_constr_conv = fz.data();
   res.func_PAR2_coupl = fp.data(); res.time_at_it = tt.data(); res.innerIters = inner.data();
+  res.func_rel_missing = frm.data();
   check(aoadmm_solve(g_ctx, &o, &res));
 
   // ---- Fac: same fields as G (cmtf_AOADMM.m:193,197-206)
@@ -301,8 +323,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   if (nlhs > 1) {
     const char* fn[] = {"f_tensors", "f_couplings", "f_constraints", "f_PAR2_couplings", "f_rel_missing", "exit_flag",
                         "OuterIterations", "func_val_conv", "func_coupl_conv", "func_constr_conv", "func_PAR2_coupl",
-                        "time_at_it", "innerIters"};
-    mxArray* out = mxCreateStructMatrix(1, 1, 13, fn);
+                        "time_at_it", "innerIters", "func_rel_missing"};
+    mxArray* out = mxCreateStructMatrix(1, 1, has_missing ? 14 : 13, fn);   /* func_rel_missing only with Z.miss (:490-492) */
     const int it = res.OuterIterations;
     auto vec = [&](const std::vector<double>& v, int len) {
       mxArray* a = mxCreateDoubleMatrix(1, len, mxREAL);
@@ -313,7 +335,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxSetField(out, 0, "f_couplings", mxCreateDoubleScalar(res.f_couplings));
     mxSetField(out, 0, "f_constraints", mxCreateDoubleScalar(res.f_constraints));
     mxSetField(out, 0, "f_PAR2_couplings", mxCreateDoubleScalar(res.f_PAR2_couplings));
-    mxSetField(out, 0, "f_rel_missing", mxCreateDoubleScalar(mxGetNaN()));
+    mxSetField(out, 0, "f_rel_missing", mxCreateDoubleScalar(has_missing ? res.f_rel_missing : mxGetNaN()));
+    if (has_missing) mxSetField(out, 0, "func_rel_missing", vec(frm, it + 1));
     if (res.exit_code == 0) {
       mxSetField(out, 0, "exit_flag", mxCreateString("maxIterations"));      /* make_exit_flag.m:4-5 */
     } else {

@@ -11,8 +11,8 @@ function [G,out] = cmtf_fun_AOADMM_hip(Z,Znorm_const,G,fh,gh,lscalar,uscalar,opt
 %
 % Function handles cannot cross to the GPU, so Z.prox_operators / Z.reg_func (cmtf_AOADMM.m:30-32) are
 % dropped and the MEX gateway re-reads the constraint descriptors Z.constraints{m}. Models the device
-% path does not cover ('custom' constraints, KL/IS/beta losses, sptensor data, Z.miss, coupling types
-% 1/2/3/5, tPARAFAC2, quadratic regularization) raise cmtf:hip:unsupported, which is caught here and
+% path does not cover ('custom' constraints, KL/IS/beta losses, sptensor data, coupling types
+% 1/2/3/5, quadratic regularization) raise cmtf:hip:unsupported, which is caught here and
 % handed to the original MATLAB implementation, so every example script keeps running.
 % Znorm_const, fh, gh, lscalar, uscalar are only needed by that fallback.
 
@@ -24,18 +24,37 @@ function [G,out] = cmtf_fun_AOADMM_hip(Z,Znorm_const,G,fh,gh,lscalar,uscalar,opt
             Zs.object{p} = double(Zs.object{p});
         end
     end
+    if isfield(Zs,'miss')                % masks (sptensor / logical, cmtf_AOADMM.m:88-119) -> dense uint8, 1 = observed
+        for p = 1:numel(Zs.miss)
+            if isempty(Zs.miss{p}), continue; end
+            if iscell(Zs.miss{p})
+                Zs.miss{p} = cellfun(@(m) uint8(m ~= 0), Zs.miss{p}, 'UniformOutput', false);
+            else
+                Zs.miss{p} = uint8(double(full(Zs.miss{p})) ~= 0);
+            end
+        end
+    end
     try
         tstart = tic;
         [G,out] = aoadmm_mex(Zs, G, options);
         if any(strcmp(options.Display,{'iter','final'}))   % cmtf_fun_AOADMM.m:44-59,462-468,498-504
-            fprintf(1,' Iter  f total      f tensors      f couplings    f constraints    f PAR2 couplings\n');
+            has_missing = isfield(out,'func_rel_missing');
+            if has_missing
+                fprintf(1,' Iter  f total      f tensors      f couplings    f constraints    f PAR2 couplings  f_rel_miss\n');
+            else
+                fprintf(1,' Iter  f total      f tensors      f couplings    f constraints    f PAR2 couplings\n');
+            end
             fprintf(1,'------ ------------ -------------  -------------- ---------------- ----------------\n');
             its = 0:out.OuterIterations;
             if strcmp(options.Display,'final'), its = out.OuterIterations; else, its = its(mod(its,options.DisplayIters)==0 | its==out.OuterIterations); end
             for it = its
                 ft = out.func_val_conv(it+1); fc = out.func_coupl_conv(it+1);
                 fz = out.func_constr_conv(it+1); fp = out.func_PAR2_coupl(it+1);
-                fprintf(1,'%6d %12f %12f %12f %17f %12f\n', it, ft+fc+fz+fp, ft, fc, fz, fp);
+                if has_missing
+                    fprintf(1,'%6d %12f %12f %12f %17f %12f %12f\n', it, ft+fc+fz+fp, ft, fc, fz, fp, out.func_rel_missing(it+1));
+                else
+                    fprintf(1,'%6d %12f %12f %12f %17f %12f\n', it, ft+fc+fz+fp, ft, fc, fz, fp);
+                end
             end
         end
         out.wall_time_hip = toc(tstart);

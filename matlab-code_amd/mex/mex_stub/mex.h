@@ -31,6 +31,8 @@ size_t mxGetNumberOfElements(const mxArray*);
 char* mxArrayToString(const mxArray*);
 void mxFree(void*);
 double mxGetNaN(void);
+void* mxGetData(const mxArray*);
+bool mxIsUint8(const mxArray*);
 mxArray* mxCreateDoubleMatrix(mwSize, mwSize, mxComplexity);
 mxArray* mxCreateDoubleScalar(double);
 mxArray* mxCreateCellMatrix(mwSize, mwSize);

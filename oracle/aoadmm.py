@@ -12,7 +12,7 @@ relative to /root/reference/):
 Scope: Frobenius loss; CP blocks (tensors and matrices) and PARAFAC2 blocks;
 coupling types 0-5 for CP modes (types 0 and 4 also for the PARAFAC2 C mode);
 every constraint of `constraints_to_prox.m`.  Out of scope (raises):
-KL/IS/beta losses (need the external L-BFGS-B MEX), EM missing data.
+KL/IS/beta losses (need the external L-BFGS-B MEX).
 
 Data model (mirrors the MATLAB structs; MATLAB's 1-based *mode numbers* inside
 `Z['modes']` and coupling ids inside `lin_coupled_modes` are kept so that the
@@ -39,7 +39,7 @@ import numpy as np
 import scipy.linalg as sla
 
 from . import prox as _prox
-from .tensor_ops import mttkrp, tensor_norm
+from .tensor_ops import full_ktensor, mttkrp, tensor_norm
 
 inf = float('inf')
 
@@ -159,8 +159,22 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
     weights = [float(w) for w in Z['weights']]
     constrained = [int(bool(c)) for c in Z['constrained_modes']]
     has_ridge = 'ridge' in Z and Z['ridge'] is not None
-    if 'miss' in Z and Z['miss'] is not None and any(m is not None for m in Z['miss']):
-        raise NotImplementedError('EM missing data is outside the oracle scope (SURVEY 8f)')
+    # EM missing data (:29, cmtf_AOADMM.m:68-121): Z['miss'][p] is a boolean array (True = observed) for a CP
+    # block, a list of K boolean matrices for a PARAFAC2 block, or None.  The imputation writes into
+    # Z.object (a local copy in the reference: MATLAB value semantics), so the data are copied first.
+    miss = Z.get('miss') if Z.get('miss') is not None else [None] * P
+    has_missing = any(mk is not None for mk in miss)
+    if has_missing:
+        Z = dict(Z)
+        Z['object'] = list(Z['object'])
+        for p in range(P):
+            if miss[p] is None:
+                continue
+            if Z['model'][p] == 'CP':
+                Z['object'][p] = np.array(Z['object'][p], dtype=np.float64, copy=True)
+            else:
+                Z['object'][p] = [np.array(Xk, dtype=np.float64, copy=True) for Xk in Z['object'][p]]
+    f_rel_missing = float('nan')
     for p in range(P):
         if Z['loss_function'][p] != 'Frobenius':
             raise NotImplementedError('only Frobenius loss is in scope (SURVEY 2.1)')
@@ -448,7 +462,11 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
         fp = np.zeros(P)
         for pp in range(P):
             md = _modes0(Z, pp)
-            if Z['model'][pp] == 'CP':
+            if Z['model'][pp] == 'CP' and miss[pp] is not None:              # :1224-1226
+                Mfull = full_ktensor([G['fac'][m] for m in md])
+                M = np.where(np.asarray(miss[pp], dtype=bool), Mfull, 0.0)
+                fp[pp] = weights[pp] * (Znorm_const[pp] - 2 * float(np.sum(np.asarray(Z['object'][pp]) * M)) + float(np.sum(M * M)))
+            elif Z['model'][pp] == 'CP':
                 if first:                                                    # :1228-1233
                     facs = [G['fac'][m] for m in md]
                     if _is_tensor(Z['object'][pp]):
@@ -460,7 +478,12 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
                     f_2 = np.sum(last_mttkrp[pp] * G['fac'][lm])
                     f_3 = np.sum(last_had[pp] * G_transp_G[lm])
                     fp[pp] = weights[pp] * (Znorm_const[pp] - 2 * f_2 + f_3)
-            else:                                                            # PAR2 :1247-1268
+            elif miss[pp] is not None:                                       # PAR2 with masks :1249-1252
+                for kk in range(_K_of(Z, pp)):
+                    Mk = G['fac'][md[0]] @ np.diag(G['fac'][md[2]][kk, :]) @ G['fac'][md[1]][kk].T
+                    fp[pp] += _fro(np.where(np.asarray(miss[pp][kk], dtype=bool), Z['object'][pp][kk] - Mk, 0.0)) ** 2
+                fp[pp] = weights[pp] * fp[pp]
+            else:                                                            # PAR2 :1254-1268
                 if (not first) and last_m[pp] == 0:
                     f_2 = np.sum(last_mttkrp[pp] * G['fac'][md[0]])
                     f_3 = np.sum(last_had[pp] * G_transp_G[md[0]])
@@ -546,6 +569,7 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
     # ================= main body =================
     f = func_eval(first=True)                                                # :32
     func_val = [f[0]]; func_coupl = [f[1]]; func_constr = [f[2]]; func_par2 = [f[3]]
+    func_rel_missing = [f_rel_missing]                                       # :37-39
     tstart = time.perf_counter()
     time_at_it = [0.0]
     it = 1
@@ -728,18 +752,46 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
                     innerIters[(m, it)] = inner_iters                          # :392
                     G_transp_G[m] = G['fac'][m].T @ G['fac'][m]               # :396
 
+        # EM imputation (:408-441): missing entries <- current model; relative change of the imputed values
+        if has_missing:
+            num_sq = den_sq = 0.0
+            for p in range(P):
+                if miss[p] is None:
+                    continue
+                md = _modes0(Z, p)
+                if Z['model'][p] == 'CP':
+                    M_full = full_ktensor([G['fac'][m] for m in md])
+                    mm = ~np.asarray(miss[p], dtype=bool)
+                    old = Z['object'][p][mm]
+                    new = M_full[mm]
+                    Z['object'][p][mm] = new
+                    num_sq += float(np.sum((new - old) ** 2))
+                    den_sq += float(np.sum(old ** 2))
+                else:
+                    for k in range(_K_of(Z, p)):
+                        M_k = G['fac'][md[0]] @ np.diag(G['fac'][md[2]][k, :]) @ G['fac'][md[1]][k].T
+                        mk = ~np.asarray(miss[p][k], dtype=bool)
+                        old = Z['object'][p][k][mk]
+                        new = M_k[mk]
+                        num_sq += float(np.sum((new - old) ** 2))
+                        den_sq += float(np.sum(old ** 2))
+                        Z['object'][p][k][mk] = new
+            f_rel_missing = float(np.sqrt(num_sq / den_sq)) if den_sq > 0 else float(np.sqrt(num_sq))   # :436-440
         f_old = f
         f = func_eval(first=False)                                            # :447
         func_val.append(f[0]); func_coupl.append(f[1]); func_constr.append(f[2]); func_par2.append(f[3])
+        func_rel_missing.append(f_rel_missing)
         time_at_it.append(time.perf_counter() - tstart)
         stop = evaluate_stopping_conditions(f, f_old, options)                 # :456
+        if has_missing:
+            stop = stop and (f_rel_missing < options['OuterRelTol'])           # :457-459
         if trace is not None:
             trace.setdefault('fac', []).append(copy.deepcopy(G['fac']))
         it += 1
 
     out = {
         'f_tensors': f[0], 'f_couplings': f[1], 'f_constraints': f[2], 'f_PAR2_couplings': f[3],
-        'f_rel_missing': float('nan'),
+        'f_rel_missing': f_rel_missing,
         'exit_flag': make_exit_flag(it, f, options),
         'OuterIterations': it - 1,
         'func_val_conv': np.array(func_val), 'func_coupl_conv': np.array(func_coupl),
@@ -750,6 +802,8 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
     for (m, i), v in innerIters.items():
         inner[m, i - 1] = v
     out['innerIters'] = inner
+    if has_missing:
+        out['func_rel_missing'] = np.array(func_rel_missing)                  # :490-492
     return G, out
 
 
@@ -758,13 +812,21 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
 # --------------------------------------------------------------------------
 
 def compute_Znorm_const(Z):
-    """functions/cmtf_AOADMM.m:124-156 (Frobenius, no missing data)."""
+    """functions/cmtf_AOADMM.m:124-156 (Frobenius): ||X||^2, or ||miss .* X||^2 for a block with a mask."""
     out = []
+    miss = Z.get('miss') if Z.get('miss') is not None else [None] * len(Z['object'])
     for p in range(len(Z['object'])):
         if Z['model'][p] == 'CP':
-            out.append(tensor_norm(Z['object'][p]) ** 2)
+            if miss[p] is not None:
+                out.append(float(np.sum(np.where(np.asarray(miss[p], dtype=bool), np.asarray(Z['object'][p]), 0.0) ** 2)))
+            else:
+                out.append(tensor_norm(Z['object'][p]) ** 2)
         else:
-            out.append(float(sum(np.linalg.norm(Xk, 'fro') ** 2 for Xk in Z['object'][p])))
+            if miss[p] is not None:
+                out.append(float(sum(np.sum(np.where(np.asarray(mk, dtype=bool), Xk, 0.0) ** 2)
+                                     for Xk, mk in zip(Z['object'][p], miss[p]))))
+            else:
+                out.append(float(sum(np.linalg.norm(Xk, 'fro') ** 2 for Xk in Z['object'][p])))
     return out
 
 

@@ -167,3 +167,81 @@ def test_rccl_one_rank_communicator(pkg):
         Fo, oo, Fg, og = run_both(pkg, e1, Z, io, options(MaxOuterIters=4), precision='f32')
         for a, b in zip(Fo['fac'], Fg['fac']):
             assert rel_fro(b, a) < 1e-4
+
+
+def _with_mask(Z, rng, frac=0.2):
+    """~20 % of the entries of every block missing at random, initialised with 0 (example_script12_CP_PAR2_EM.m:115-147)."""
+    Z = dict(Z)
+    Z['object'] = list(Z['object'])
+    miss = []
+    for p, obj in enumerate(Z['object']):
+        if Z['model'][p] == 'CP':
+            X = np.array(obj, dtype=float)
+            mask = np.ones(X.shape, dtype=bool)
+            mask.flat[rng.choice(mask.size, int(frac * mask.size), replace=False)] = False
+            X[~mask] = 0.0
+            Z['object'][p] = X
+            miss.append(mask)
+        else:
+            Xs, ms = [], []
+            for Xk in obj:
+                Xk = np.array(Xk, dtype=float)
+                mk = np.ones(Xk.shape, dtype=bool)
+                mk.flat[rng.choice(mk.size, int(frac * mk.size), replace=False)] = False
+                Xk[~mk] = 0.0
+                Xs.append(Xk); ms.append(mk)
+            Z['object'][p] = Xs
+            miss.append(ms)
+    Z['miss'] = miss
+    return Z
+
+
+def _compare_em(oo, og):
+    assert np.allclose(og['func_rel_missing'][1:], oo['func_rel_missing'][1:], rtol=1e-7, atol=1e-12)
+    assert np.isnan(og['func_rel_missing'][0])
+    assert abs(og['f_rel_missing'] - oo['f_rel_missing']) <= 1e-7 * abs(oo['f_rel_missing']) + 1e-12
+
+
+def test_em_missing_cp(pkg, eng):
+    """EM imputation (cmtf_fun_AOADMM.m:408-441) on a CP tensor, ragged first mode (padding rows), TV + non-negativity."""
+    rng = np.random.default_rng(31)
+    Z, io, _ = cp_model((37, 22, 19), 3, rng, [('non-negativity',), ('non-negativity',), ('TV regularization', 1e-3)])
+    Z = _with_mask(Z, rng)
+    Fo, oo, Fg, og = run_both(pkg, eng, Z, io, options(MaxOuterIters=12))
+    compare(Fo, oo, Fg, og)
+    _compare_em(oo, og)
+
+
+def test_em_missing_matrix_and_stop_rule(pkg, eng):
+    """Matrix block (transposed copy imputed as well) + the extra stopping rule f_rel_missing < OuterRelTol (:457-459)."""
+    rng = np.random.default_rng(32)
+    Z, io, _ = cp_model((30, 26), 3, rng, [('non-negativity',), None], noise=0.0)
+    Z = _with_mask(Z, rng, frac=0.1)
+    opt = options(MaxOuterIters=400, AbsFuncTol=1e-4, OuterRelTol=1e-3)
+    Fo, oo, Fg, og = run_both(pkg, eng, Z, io, opt)
+    assert og['OuterIterations'] == oo['OuterIterations'] and og['OuterIterations'] < 400
+    for a, b in zip(Fo['fac'], Fg['fac']):
+        assert rel_fro(b, a) < 1e-6
+    _compare_em(oo, og)
+
+
+def test_em_missing_cp_parafac2_script12(pkg, eng):
+    """example_script12_CP_PAR2_EM.m: coupled CP + PARAFAC2, ~20 % missing in both blocks."""
+    from helpers import script1_model
+    rng = np.random.default_rng(33)
+    Z, io = script1_model(rng, dims=(20, 30, 40), K=8, Jk=30, noise=0.05)
+    Z = _with_mask(Z, rng)
+    Fo, oo, Fg, og = run_both(pkg, eng, Z, io, options(MaxOuterIters=10))
+    compare_par2(Fo, oo, Fg, og)
+    _compare_em(oo, og)
+
+
+def test_em_missing_fp32_tensor(pkg, eng):
+    """fp32-resident tensor: imputation and statistics in fp32/fp64 mix, stated tolerance 1e-4."""
+    rng = np.random.default_rng(34)
+    Z, io, _ = cp_model((41, 33, 28), 3, rng, [('non-negativity',)] * 3)
+    Z = _with_mask(Z, rng)
+    Fo, oo, Fg, og = run_both(pkg, eng, Z, io, options(MaxOuterIters=8), precision='f32')
+    for a, b in zip(Fo['fac'], Fg['fac']):
+        assert rel_fro(b, a) < 1e-4
+    assert np.allclose(og['func_rel_missing'][1:], oo['func_rel_missing'][1:], rtol=1e-3)

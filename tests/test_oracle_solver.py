@@ -93,3 +93,39 @@ def test_not_positive_definite_raises_like_matlab():
     G['fac'][1][:] = 0.0          # zero factor => C = 0, rho = 0, B singular => chol throws (:142)
     with pytest.raises(np.linalg.LinAlgError):
         OA.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=1), init=G)
+
+
+def _masked_cp_model(rng, dims=(15, 12, 10), R=2, frac=0.2):
+    from helpers import cp_model
+    Z, io, _ = cp_model(dims, R, rng, [('non-negativity',)] * 3, noise=0.0)
+    mask = np.ones(dims, dtype=bool)
+    n = mask.size
+    mask.flat[rng.choice(n, int(frac * n), replace=False)] = False
+    X = np.array(Z['object'][0])
+    Xtrue = X.copy()
+    X[~mask] = 0.0                                   # example_script12_CP_PAR2_EM.m:143
+    Z['object'] = [X]
+    Z['miss'] = [mask]
+    return Z, io, Xtrue, mask
+
+
+def test_em_missing_data_recovers_noise_free_entries():
+    """example_script12 family (EM imputation, cmtf_fun_AOADMM.m:408-441): with noise-free low-rank data and 20 %
+    of the entries missing, the imputed model reproduces the held-out entries, f_tensors counts observed entries
+    only and func_rel_missing decreases."""
+    from helpers import options
+    from oracle.tensor_ops import full_ktensor
+    rng = np.random.default_rng(3)
+    Z, io, Xtrue, mask = _masked_cp_model(rng)
+    Zhat, Fac, G, out = OA.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=400, MaxInnerIters=5), init='random',
+                                       init_options=io, rng=rng)
+    M = full_ktensor(Fac['fac'])
+    assert np.linalg.norm((M - Xtrue)[~mask]) / np.linalg.norm(Xtrue[~mask]) < 5e-2
+    assert out['f_tensors'] < 1e-4
+    frm = out['func_rel_missing']
+    assert np.isnan(frm[0]) and frm[-1] < frm[2]
+    # the caller's data are not modified (MATLAB value semantics)
+    assert np.all(Z['object'][0][~mask] == 0.0)
+    # f_tensors is the observed-entry residual
+    direct = np.sum(((Z['object'][0] - M) ** 2)[mask])
+    assert abs(out['f_tensors'] - direct) < 1e-10
