@@ -12,7 +12,12 @@ struct ProxSpec {
   const double* Lmat = nullptr;    // device, AOADMM_C_QUADRATIC only
 };
 
-bool prox_is_fusable(int type);     // element-wise or row-wise: folded into the primal kernel
+bool prox_is_fusable(int type);
+// constraints with a reg_func entry (constraints_to_prox.m): their value enters f_tensors (cmtf_fun_AOADMM.m:1272-1288)
+inline bool prox_has_reg_value(int t) {
+  return t == AOADMM_C_L1_REG || t == AOADMM_C_L0_REG || t == AOADMM_C_L2_REG || t == AOADMM_C_RIDGE ||
+         t == AOADMM_C_GL_SMOOTH || t == AOADMM_C_TV;
+}     // element-wise or row-wise: folded into the primal kernel
 size_t prox_ws_bytes(int type, int64_t rows, int R);
 
 // Z_out = prox(V, rho) for any catalogue entry; rho read from device memory.

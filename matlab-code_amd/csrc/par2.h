@@ -62,6 +62,8 @@ void par2_c_rowsolve(const double* a, const double* rho, const double* L, const 
 // res[k] = ||X_k - A D_k B_k'||_F^2                                                       (:1262-1264)
 void par2_residual(const double* X, const double* A, const double* B, const double* Cfac, const P2Dims& d,
                    double* res, hipStream_t s);
+// regv[k] = reg_func(B_k) of a regularisation-type constraint on the B_k mode            (:1279-1281)
+void par2_reg_values(const double* B, int type, double eta, const P2Dims& d, double* regv, hipStream_t s);
 // q[k][0..3] = ||B_k - P_k DeltaB||^2, ||B_k||^2, ||B_k - Z_k||^2 (Z nullable), 0          (:1355, :1337)
 void par2_b_gaps(const double* B, const double* P, const double* DeltaB, const double* Z, const P2Dims& d,
                  double* q, hipStream_t s);

@@ -574,6 +574,44 @@ __global__ __launch_bounds__(kP2Threads) void par2_b_gaps_k(const double* B, con
   s0 = block_sum_pow2(s0, red); s1 = block_sum_pow2(s1, red); s2 = block_sum_pow2(s2, red); s3 = block_sum_pow2(s3, red);
   if (threadIdx.x == 0) { q[(int64_t)k * 4] = s0; q[(int64_t)k * 4 + 1] = s1; q[(int64_t)k * 4 + 2] = s2; q[(int64_t)k * 4 + 3] = s3; }
 }
+// regv[k] = reg_func(B_k) for the regularisation-type constraints (constraints_to_prox.m:50,54,58,62,75,81;
+// summed over the slabs at cmtf_fun_AOADMM.m:1279-1281).  One workgroup per slab, fixed summation order.
+__global__ __launch_bounds__(kP2Threads) void par2_reg_k(const double* B, int type, double eta, P2Dims d, double* regv) {
+  __shared__ double red[kP2Threads];
+  const int k = blockIdx.x, R = d.R;
+  const int64_t o = d.off[k];
+  const int Jk = (int)(d.off[k + 1] - o);
+  const double* Bk = B + o * R;
+  double tot = 0.0;
+  if (type == AOADMM_C_L2_REG) {                     // eta * sum_r ||B_k(:,r)||_2
+    for (int r = 0; r < R; ++r) {
+      double a = 0.0;
+      for (int j = threadIdx.x; j < Jk; j += blockDim.x) { const double v = Bk[j + (int64_t)Jk * r]; a += v * v; }
+      tot += sqrt(block_sum_pow2(a, red));
+    }
+  } else {
+    double a = 0.0;
+    for (int e = threadIdx.x; e < Jk * R; e += blockDim.x) {
+      const int r = e / Jk, j = e - r * Jk;
+      const double v = Bk[e];
+      switch (type) {
+        case AOADMM_C_L1_REG: a += fabs(v); break;
+        case AOADMM_C_L0_REG: a += (v != 0.0) ? 1.0 : 0.0; break;
+        case AOADMM_C_RIDGE: a += v * v; break;
+        case AOADMM_C_TV: if (j + 1 < Jk) a += Bk[e + 1] - v; break;               // no abs(): quirk of :81
+        case AOADMM_C_GL_SMOOTH: if (j + 1 < Jk) { const double dd = Bk[e + 1] - v; a += dd * dd; } break;
+        default: break;
+      }
+    }
+    tot = block_sum_pow2(a, red);
+  }
+  if (threadIdx.x == 0) regv[k] = eta * tot;
+}
+void par2_reg_values(const double* B, int type, double eta, const P2Dims& d, double* regv, hipStream_t s) {
+  par2_reg_k<<<d.K, kP2Threads, 0, s>>>(B, type, eta, d, regv);
+  AO_KERNEL_CHECK();
+}
+
 void par2_b_gaps(const double* B, const double* P, const double* DeltaB, const double* Z, const P2Dims& d, double* q,
                  hipStream_t s) {
   par2_b_gaps_k<<<d.K, kP2Threads, 0, s>>>(B, P, DeltaB, Z, d, q);

@@ -79,7 +79,7 @@ struct Par2Block {
   DevBuf DeltaB, DeltaBold, P, Pold, muDB;        // state (G.DeltaB, G.P, G.mu_DeltaB)
   bool has_DeltaB = false;
   std::vector<char> have_P, have_mu;
-  DevBuf W, T1, GB, Ak, Lk, rhok, part, norms, res, q, Csys, ac, Lc, rhoc, rhomax;
+  DevBuf W, T1, GB, Ak, Lk, rhok, part, norms, res, q, regv, Csys, ac, Lc, rhoc, rhomax;
   P2Dims dims() const {
     P2Dims d;
     d.K = K; d.I = I; d.R = R; d.off = off_d.as<int64_t>(); d.off_h = off_h.data(); d.Jtot = Jtot; d.Jmax = Jmax;

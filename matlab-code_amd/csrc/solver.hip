@@ -189,10 +189,6 @@ void Engine::model_end() {
     if (mi.pos == 1) {
       // check_data_input.m:33-35
       AO_REQUIRE(mi.coupling < 0, "Coupling in 2. mode (the varying mode) of Parafac2 decomposition not supported.");
-      const int ty = mi.prox.type;
-      if (mi.constrained && (ty == AOADMM_C_L1_REG || ty == AOADMM_C_L0_REG || ty == AOADMM_C_L2_REG ||
-                             ty == AOADMM_C_RIDGE || ty == AOADMM_C_GL_SMOOTH || ty == AOADMM_C_TV))
-        throw Error(AOADMM_ERR_UNSUPPORTED, "regularisation-type constraints on the PARAFAC2 B_k mode are not in the device path yet");
     }
     if (mi.pos == 2 && mi.coupling >= 0)
       throw Error(AOADMM_ERR_UNSUPPORTED, "coupling of the PARAFAC2 C mode is not in the device path yet (use the MATLAB path)");
@@ -1178,6 +1174,12 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
           double pen = 0.0;
           for (int k = 1; k < b.K; ++k) pen += q[4 * k + 3];
           ft += mB.prox.p0 * pen;
+        }
+        if (mB.constrained && prox_has_reg_value(mB.prox.type)) {          // sum_k reg_func(B_k) (:1279-1281)
+          std::vector<double> rv(b.K);
+          AO_HIP(hipMemcpyAsync(rv.data(), b.regv.p, b.K * sizeof(double), hipMemcpyDeviceToHost, stream_));
+          AO_HIP(hipStreamSynchronize(stream_));
+          for (int k = 0; k < b.K; ++k) ft += rv[k];
         }
         if (mB.constrained) {
           const double g = gz / b.K;                                                            // :1339

@@ -94,7 +94,7 @@ void Engine::par2_ensure_work(TensorInfo& t) {
   b.GB.ensure((size_t)b.K * RR); b.Lk.ensure((size_t)b.K * RR); b.Lc.ensure((size_t)b.K * RR);
   b.rhok.ensure((size_t)b.K * 8); b.rhoc.ensure((size_t)b.K * 8); b.rhomax.ensure(64);
   b.part.ensure((size_t)b.K * RR); b.norms.ensure((size_t)b.K * 8 * 8);
-  b.res.ensure((size_t)b.K * 8); b.q.ensure((size_t)b.K * 4 * 8);
+  b.res.ensure((size_t)b.K * 8); b.q.ensure((size_t)b.K * 4 * 8); b.regv.ensure((size_t)b.K * 8);
   b.Csys.ensure(RR); b.ac.ensure((size_t)b.K * b.R * 8);
   ModeInfo& mB = modes_[t.modes[1]];
   const size_t nB = (size_t)mB.rows * mB.R * sizeof(double);
@@ -226,6 +226,8 @@ void Engine::par2_objective_enqueue(TensorInfo& t) {
   ModeInfo& mC = modes_[t.modes[2]];
   par2_residual(b.X.d(), mA.fac.d(), mB.fac.d(), mC.fac.d(), d, b.res.d(), stream_);
   par2_b_gaps(mB.fac.d(), b.P.d(), b.DeltaB.d(), mB.constrained ? mB.Z.d() : nullptr, d, b.q.d(), stream_);
+  if (mB.constrained && prox_has_reg_value(mB.prox.type))
+    par2_reg_values(mB.fac.d(), mB.prox.type, mB.prox.p0, d, b.regv.d(), stream_);
 }
 
 }  // namespace aoadmm

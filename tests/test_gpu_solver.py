@@ -245,3 +245,21 @@ def test_em_missing_fp32_tensor(pkg, eng):
     for a, b in zip(Fo['fac'], Fg['fac']):
         assert rel_fro(b, a) < 1e-4
     assert np.allclose(og['func_rel_missing'][1:], oo['func_rel_missing'][1:], rtol=1e-3)
+
+
+@pytest.mark.parametrize('cB', [('GL smoothness', 1.0), ('TV regularization', 0.01), ('l1 regularization', 0.01),
+                                ('ridge', 0.1), ('l2 regularization', 0.05)])
+def test_parafac2_regularised_Bk(pkg, eng, cB):
+    """example_script1a family: a regularisation-type constraint on the PARAFAC2 B_k mode ('GL smoothness' there);
+    its value sum_k reg_func(B_k) enters f_tensors (cmtf_fun_AOADMM.m:1279-1281)."""
+    from helpers import par2_slabs
+    rng = np.random.default_rng(41)
+    I, R, K, J = 30, 3, 5, 44          # regular PARAFAC2: the reference builds ONE Laplacian from the first slab size
+    X, _ = par2_slabs(I, [J] * K, R, rng, noise=0.1)             # (constraints_to_prox.m:70), so GL needs equal J_k
+    Z = dict(loss_function=['Frobenius'], model=['PAR2'], modes=[[1, 2, 3]], size=[I, [J] * K, K],
+             coupling=dict(lin_coupled_modes=[0, 0, 0], coupling_type=[], coupl_trafo_matrices=[None] * 3),
+             constrained_modes=[0, 1, 1], constraints=[None, cB, ('non-negativity',)], weights=[1.0], object=[X])
+    distr = [lambda a, b: rng.standard_normal((a, b)), lambda a, b: rng.standard_normal((a, b)),
+             lambda a, b: rng.random((a, b)) + 0.1]
+    io = dict(lambdas_init=[[1] * R], nvecs=0, distr=distr, normalize=1)
+    compare_par2(*run_both(pkg, eng, Z, io, options(MaxOuterIters=8)))
