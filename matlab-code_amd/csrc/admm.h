@@ -9,14 +9,28 @@ namespace aoadmm {
 struct ProxSpec {
   int type = AOADMM_C_NONE;
   double p0 = 0.0, p1 = 0.0;       // constraint parameters (eta | l,u | nn)
-  const double* Lmat = nullptr;    // device, AOADMM_C_QUADRATIC only
+  // AOADMM_C_QUADRATIC only (device pointers, see QuadPrep): L = U diag(w) U'
+  const double* Lmat = nullptr;
+  const double* LU = nullptr;
+  const double* LUt = nullptr;
+  const double* Lw = nullptr;
+};
+
+// 'quadratic regularization' (constraints_to_prox.m:62-67): prox(x,rho) = (2*eta/rho*L + I) \ x with a fixed
+// user matrix L.  rho changes every outer iteration, L does not: L is diagonalised once on the host
+// (symmetric L required) and the prox becomes U * diag(1/(2*eta/rho*w_i + 1)) * U' * x, two small GEMMs.
+struct QuadPrep {
+  DevBuf L, U, Ut, w;
+  int64_t n = 0;
+  void build(const double* L_host, int64_t rows, hipStream_t s);
+  void attach(ProxSpec& ps) const { ps.Lmat = L.d(); ps.LU = U.d(); ps.LUt = Ut.d(); ps.Lw = w.d(); }
 };
 
 bool prox_is_fusable(int type);
 // constraints with a reg_func entry (constraints_to_prox.m): their value enters f_tensors (cmtf_fun_AOADMM.m:1272-1288)
 inline bool prox_has_reg_value(int t) {
   return t == AOADMM_C_L1_REG || t == AOADMM_C_L0_REG || t == AOADMM_C_L2_REG || t == AOADMM_C_RIDGE ||
-         t == AOADMM_C_GL_SMOOTH || t == AOADMM_C_TV;
+         t == AOADMM_C_GL_SMOOTH || t == AOADMM_C_TV || t == AOADMM_C_QUADRATIC;
 }     // element-wise or row-wise: folded into the primal kernel
 size_t prox_ws_bytes(int type, int64_t rows, int R);
 

@@ -2,6 +2,7 @@
 // Reference: functions/cmtf_fun_AOADMM.m:591-623 (ADMM_constrained_only), :1420-1429
 // (update_constraint), :1079-1096 (eval_res_ADMM_constr); functions/constraints_to_prox.m.
 #include "admm.h"
+#include "hosteig.h"
 
 namespace aoadmm {
 
@@ -1007,6 +1008,43 @@ __global__ void prox_rows_k(ColArgs a, const AdmmCtl* ctl) {
     if (r < a.R) a.Z[i + a.ldz * r] = z[r];
 }
 
+// ---- 'quadratic regularization' ------------------------------------------------------------------
+void QuadPrep::build(const double* L_host, int64_t rows, hipStream_t s) {
+  AO_REQUIRE(L_host != nullptr && rows > 0, "quadratic regularization needs its matrix L");
+  if (rows > 4096) throw Error(AOADMM_ERR_UNSUPPORTED, "quadratic regularization: matrices beyond 4096 x 4096 are not diagonalised on the host");
+  n = rows;
+  std::vector<double> A(L_host, L_host + (size_t)rows * rows), wv, Uv;
+  double asym = 0.0, nrm = 0.0;
+  for (int64_t j = 0; j < rows; ++j)
+    for (int64_t i = 0; i < rows; ++i) {
+      const double d = A[(size_t)i + (size_t)rows * j] - A[(size_t)j + (size_t)rows * i];
+      asym += d * d; nrm += A[(size_t)i + (size_t)rows * j] * A[(size_t)i + (size_t)rows * j];
+    }
+  if (std::sqrt(asym) > 1e-12 * std::sqrt(nrm))
+    throw Error(AOADMM_ERR_UNSUPPORTED, "quadratic regularization with a non-symmetric L is not in the device path");
+  const int sweeps = host_sym_eig(rows, A, wv, Uv);
+  AO_REQUIRE(sweeps >= 0, "eigendecomposition of the quadratic-regularization matrix did not converge");
+  std::vector<double> Utv((size_t)rows * rows);
+  for (int64_t j = 0; j < rows; ++j)
+    for (int64_t i = 0; i < rows; ++i) Utv[(size_t)j + (size_t)rows * i] = Uv[(size_t)i + (size_t)rows * j];
+  const size_t nn = (size_t)rows * rows * sizeof(double);
+  L.alloc(nn); U.alloc(nn); Ut.alloc(nn); w.alloc((size_t)rows * sizeof(double));
+  AO_HIP(hipMemcpyAsync(L.p, L_host, nn, hipMemcpyHostToDevice, s));
+  AO_HIP(hipMemcpyAsync(U.p, Uv.data(), nn, hipMemcpyHostToDevice, s));
+  AO_HIP(hipMemcpyAsync(Ut.p, Utv.data(), nn, hipMemcpyHostToDevice, s));
+  AO_HIP(hipMemcpyAsync(w.p, wv.data(), (size_t)rows * sizeof(double), hipMemcpyHostToDevice, s));
+  AO_HIP(hipStreamSynchronize(s));
+}
+
+// W(i,:) *= 1 / (2*eta/rho*w_i + 1)
+__global__ void quad_scale_k(double* W, int64_t rows, int R, const double* w, double eta, const double* rho, double rho_mul,
+                             const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  const double g = 2.0 * (eta / (rho[0] * rho_mul));
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < rows * R; e += (int64_t)gridDim.x * blockDim.x)
+    W[e] = W[e] / (g * w[e % rows] + 1.0);
+}
+
 static constexpr int64_t kTvLdsRows = 8192;
 
 size_t prox_ws_bytes(int type, int64_t rows, int R) {
@@ -1016,6 +1054,7 @@ size_t prox_ws_bytes(int type, int64_t rows, int R) {
     case AOADMM_C_UNIMODAL: return (size_t)R * 16 * (rows + 2) * sizeof(double);
     case AOADMM_C_GL_SMOOTH: return (size_t)R * rows * sizeof(double);
     case AOADMM_C_ORTHONORMAL: return (size_t)R * rows * sizeof(double);
+    case AOADMM_C_QUADRATIC: return (size_t)R * rows * sizeof(double);
     default: return 16;
   }
 }
@@ -1071,6 +1110,16 @@ void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, 
     case AOADMM_C_UNIMODAL: prox_unimodal_k<<<R, 64, 0, s>>>(a, ctl); break;
     case AOADMM_C_GL_SMOOTH: prox_gl_k<<<R, 64, 0, s>>>(a, ctl); break;
     case AOADMM_C_ORTHONORMAL: prox_ortho_k<<<1, 256, (size_t)R * R * sizeof(double), s>>>(a, ctl); break;
+    case AOADMM_C_QUADRATIC: {                       // (2*eta/rho*L + I) \ x = U diag(1/(2 eta/rho w + 1)) U' x   (:66)
+      AO_REQUIRE(ps.LU && ps.LUt && ps.Lw, "quadratic regularization: matrix not prepared");
+      gemm_small(ws, rows, ps.LUt, rows, V, ldv, rows, (int)rows, R, 0, coef(1.0), 0.0, ctl, s);
+      int64_t nb = cdiv(rows * R, 256);
+      if (nb > 1024) nb = 1024;
+      quad_scale_k<<<(unsigned)nb, 256, 0, s>>>(ws, rows, R, ps.Lw, ps.p0, rho_dev, rho_mul, ctl);
+      AO_KERNEL_CHECK();
+      gemm_small(Zout, ldz, ps.LU, rows, ws, rows, rows, (int)rows, R, 0, coef(1.0), 0.0, ctl, s);
+      break;
+    }
     default:
       throw Error(AOADMM_ERR_UNSUPPORTED, fmt("constraint id %d has no device prox (route to the MATLAB path)", ps.type));
   }

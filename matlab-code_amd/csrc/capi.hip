@@ -309,7 +309,6 @@ int aoadmm_op_prox(aoadmm_ctx* ctx, int constraint, const double* params, int n_
                    const double* X, int64_t rows, int R, double rho, double* out) {
   CTX_OR_FAIL(ctx);
   return guarded([&] {
-    (void)Lmat;
     AO_REQUIRE(X && out && rows > 0 && R > 0 && R <= kMaxRank, "bad arguments");
     Engine& e = *ctx->eng;
     AO_HIP(hipSetDevice(e.device()));
@@ -318,8 +317,10 @@ int aoadmm_op_prox(aoadmm_ctx* ctx, int constraint, const double* params, int n_
     z.alloc((size_t)rows * R * 8);
     h2d(r, &rho, 1, e.stream());
     ws.alloc(prox_ws_bytes(constraint, rows, R));
-    prox_apply(make_spec(constraint, params, n_params), x.d(), rows, z.d(), rows, rows, R, r.d(), 1.0, ws.d(), nullptr,
-               e.stream());
+    ProxSpec ps = make_spec(constraint, params, n_params);
+    QuadPrep qp;
+    if (constraint == AOADMM_C_QUADRATIC) { qp.build(Lmat, rows, e.stream()); qp.attach(ps); }
+    prox_apply(ps, x.d(), rows, z.d(), rows, rows, R, r.d(), 1.0, ws.d(), nullptr, e.stream());
     d2h(out, z, rows * R, e.stream());
   });
 }
@@ -330,7 +331,6 @@ int aoadmm_op_admm_constrained(aoadmm_ctx* ctx, const double* A, const double* B
                                int* inner_iters) {
   CTX_OR_FAIL(ctx);
   return guarded([&] {
-    (void)Lmat;
     AO_REQUIRE(A && Bsys && fac && Z && mu && rows > 0 && R > 0 && R <= kMaxRank && max_inner >= 1, "bad arguments");
     Engine& e = *ctx->eng;
     hipStream_t s = e.stream();
@@ -357,6 +357,8 @@ int aoadmm_op_admm_constrained(aoadmm_ctx* ctx, const double* A, const double* B
     AdmmMode am;
     am.A = a.d(); am.L = l.d(); am.rho = rh.d(); am.fac = f.d(); am.Z = z.d(); am.mu = m.d();
     am.rows = rows; am.R = R; am.prox = make_spec(constraint, params, n_params);
+    QuadPrep qp;
+    if (constraint == AOADMM_C_QUADRATIC) { qp.build(Lmat, rows, s); qp.attach(am.prox); }
     admm_constrained_loop(am, part.d(), V.d(), Zn.d(), ws.d(), ctl.as<AdmmCtl>(), max_inner, tol_pr, tol_du, s);
     AdmmCtl h;
     AO_HIP(hipMemcpyAsync(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost, s));

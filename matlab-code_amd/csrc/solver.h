@@ -53,7 +53,8 @@ struct ModeInfo {
   int coupling = -1;
   bool constrained = false;
   ProxSpec prox;
-  DevBuf Lmat, H, H2;
+  DevBuf H, H2;
+  QuadPrep quad;           // quadratic regularization: L and its eigendecomposition
   int64_t hr = 0, hc = 0, h2r = 0, h2c = 0;
   double ridge = 0.0;
   DevBuf fac, Z, mu, muD;

@@ -138,10 +138,16 @@ void Engine::set_constraint(int mode, int type, const double* params, int np, co
     case AOADMM_C_L2_REG: case AOADMM_C_RIDGE: case AOADMM_C_GL_SMOOTH: case AOADMM_C_TV: need(1); break;
     case AOADMM_C_TPARAFAC2: need(1); break;
     case AOADMM_C_QUADRATIC:
-      throw Error(AOADMM_ERR_UNSUPPORTED, "'quadratic regularization' (dense user matrix) has no device prox yet (route to the MATLAB path)");
+      need(1);
+      AO_REQUIRE(mi.defined, "quadratic regularization: define the mode before its constraint");
+      if (mi.slabs) throw Error(AOADMM_ERR_UNSUPPORTED, "quadratic regularization on the PARAFAC2 B_k mode is not in the device path");
+      AO_REQUIRE(Lmat != nullptr, "quadratic regularization on mode %d needs its matrix L (constraints{m}{3})", mode + 1);
+      AO_HIP(hipSetDevice(device_));
+      mi.quad.build(Lmat, mi.rows, stream_);
+      mi.quad.attach(mi.prox);
+      break;
     default: break;
   }
-  (void)Lmat;
 }
 
 static void upload_small(DevBuf& b, const double* host, int64_t n, hipStream_t s) {
@@ -1054,6 +1060,12 @@ void Engine::eval_objective_enqueue(bool first) {
       const int ty = mi.prox.type;
       if (ty == AOADMM_C_L2_REG) {
         reg_value(sm + 3, ty, mi.prox.p0, mi.fac.d(), mi.rows, mi.R, redws_.d(), stream_);
+      } else if (ty == AOADMM_C_QUADRATIC) {       // eta*trace(x'*L*x) (:67): L*x into the prox workspace, then <x, L*x>
+        gemm_small(mi.proxws.d(), mi.rows, mi.prox.Lmat, mi.rows, mi.fac.d(), mi.rows, mi.rows, (int)mi.rows, mi.R, 0,
+                   coef(1.0), 0.0, nullptr, stream_);
+        ReduceTask k;
+        k.kind = RT_DOT; k.slot = sm + 3; k.x = mi.fac.d(); k.y = mi.proxws.d(); k.n = nm; k.scale = mi.prox.p0;
+        rb.add(k);
       } else if (ty == AOADMM_C_L1_REG || ty == AOADMM_C_L0_REG || ty == AOADMM_C_RIDGE || ty == AOADMM_C_GL_SMOOTH ||
                  ty == AOADMM_C_TV) {
         ReduceTask k;
@@ -1206,9 +1218,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
       const double nf = std::sqrt(sm[0]);
       if (mi.constrained) {
         const int ty = mi.prox.type;
-        if (ty == AOADMM_C_L1_REG || ty == AOADMM_C_L0_REG || ty == AOADMM_C_L2_REG || ty == AOADMM_C_RIDGE ||
-            ty == AOADMM_C_GL_SMOOTH || ty == AOADMM_C_TV)
-          ft += sm[3];                                                         // reg_func (:1272-1288)
+        if (prox_has_reg_value(ty)) ft += sm[3];                               // reg_func (:1272-1288)
         const double g = std::sqrt(sm[1]) / nf;                               // :1341
         fcon += g;
         if (g != 0.0) ++ncon;

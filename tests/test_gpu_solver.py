@@ -263,3 +263,18 @@ def test_parafac2_regularised_Bk(pkg, eng, cB):
              lambda a, b: rng.random((a, b)) + 0.1]
     io = dict(lambdas_init=[[1] * R], nvecs=0, distr=distr, normalize=1)
     compare_par2(*run_both(pkg, eng, Z, io, options(MaxOuterIters=8)))
+
+
+def test_cp_quadratic_regularization(pkg, eng):
+    """{'quadratic regularization', eta, L} with a dense symmetric L (constraints_to_prox.m:62-67): the device prox
+    uses L = U diag(w) U' (diagonalised once on the host), the oracle solves (2 eta/rho L + I) \\ x directly."""
+    rng = np.random.default_rng(51)
+    n = 35
+    W = rng.random((n, n)); W = np.triu(W, 1); W = W + W.T
+    L = np.diag(W.sum(axis=1)) - W                       # weighted graph Laplacian
+    Z, io, _ = cp_model((n, 22, 19), 3, rng, [('quadratic regularization', 0.02, L), ('non-negativity',), None])
+    compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=12)))
+    x = rng.standard_normal((n, 4))
+    got = eng.prox(('quadratic regularization', 0.02, L), x, 0.7)
+    ref = np.linalg.solve(2 * 0.02 / 0.7 * L + np.eye(n), x)
+    assert rel_fro(got, ref) < 1e-12
