@@ -69,7 +69,8 @@ void constraint_update(const ProxSpec& ps, const double* fac, double* Z, double*
 
 // residual bookkeeping at the end of a generic inner iteration; per participating mode a block of
 // 8 slots: [0]=||fac-Z||^2 [1]=||fac||^2 [2]=||mu||^2 [3]=||Z-Zold||^2
-//          [4]=||fac-T(Delta)||^2 [5]=||mu_Delta||^2 [6]=||T(Delta-Delta_old)||^2 [7]=flags as double
+//          [4]=||Tf(fac)-Sd(Delta)||^2 [5]=||mu_Delta||^2 [6]=||Sd(Delta-Delta_old)||^2
+//          [7]=denominator of the primal coupling residual (||fac||^2, or ||Tf(fac)||^2 for types 1, 2)
 struct FinalizeArgs {
   const double* slots[8];
   int constrained[8];

@@ -1227,7 +1227,7 @@ __global__ void admm_finalize_generic_k(FinalizeArgs fa, AdmmCtl* ctl) {
   for (int m = 0; m < fa.nmodes; ++m) {
     const double* s = fa.slots[m];
     if (fa.coupled[m]) {                        // eval_res_ADMM_coupl_case* (:1099-1210)
-      prc += sqrt(s[4]) / sqrt(s[1]);
+      prc += sqrt(s[4]) / sqrt(s[7]);             // [7] = ||C||^2, or ||H*C||^2 / ||C*H||^2 for types 1, 2
       const double sc = sqrt(s[5]);
       duc += sc > 0 ? sqrt(s[6]) / sc : sqrt(s[6]);
       ++nc;

@@ -83,6 +83,7 @@ struct SysBuild {
   int R;
   double *C, *rho, *Bsys, *L;
   double* Binv = nullptr;   // optional: inv(L*L') (used by the fused ADMM row kernel)
+  const double* Madd = nullptr;   // optional R x R: the factored matrix also gets + rho/2 * Madd (coupling type 2: H*H')
   AdmmCtl* ctl;
 };
 void sys_build(const SysBuild& sb, hipStream_t s);
@@ -90,5 +91,13 @@ void sys_build(const SysBuild& sb, hipStream_t s);
 void ctl_reset(AdmmCtl* ctl, hipStream_t s);
 // L = chol(B) only (B symmetric R x R); flag -> ctl->notpd
 void chol_only(double* L, const double* B, int R, AdmmCtl* ctl, hipStream_t s);
+
+// B = V diag(w) V' for a symmetric n x n matrix, n <= 64 (cyclic Jacobi, one wave)
+void sym_eig_small(const double* B, int n, double* w, double* V, hipStream_t s);
+// BB <- AA \ BB, AA symmetric positive definite q x q (destroyed), BB q x nrhs; failure -> ctl->notpd
+void spd_solve_left(double* AA, int64_t q, double* BB, int nrhs, AdmmCtl* ctl, hipStream_t s);
+// W(i,j) /= rho/2*(lam_mul*lam[i] + shift_mul) + mu[j]
+void sylv_scale(double* W, int64_t rows, int R, const double* lam, const double* mu, const double* rho, double lam_mul,
+                double shift_mul, const AdmmCtl* ctl, hipStream_t s);
 
 }  // namespace aoadmm

@@ -425,6 +425,7 @@ __global__ __launch_bounds__(64) void sys_build_k(SysBuild sb) {
     if (c == t) b += sb.ridge + sb.bsum_half;    // :117-119, :126
     if (mine && c < R) sb.Bsys[t + R * c] = b;
     if (c == t) b += sb.nrho * (rho / 2);        // :141 / :269-271
+    if (sb.Madd && mine && c < R) b += (rho / 2) * sb.Madd[t + R * c];   // :314
     row[c] = (mine && c < R) ? b : 0.0;
   }
   // chol(B','lower') (:142), right-looking.  Lane t keeps L(t, 0..t); its entries right of the diagonal
@@ -518,6 +519,134 @@ void ctl_reset(AdmmCtl* ctl, hipStream_t s) {
 }
 void chol_only(double* L, const double* B, int R, AdmmCtl* ctl, hipStream_t s) {
   chol_only_k<<<1, 256, (size_t)R * R * sizeof(double), s>>>(L, B, R, ctl);
+  AO_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// Symmetric eigendecomposition of a small matrix (n <= 64) by cyclic Jacobi, one wave, matrix and
+// eigenvectors in LDS: B = V diag(w) V'.  Used by the Sylvester-type primal updates of the transformed
+// couplings (cmtf_fun_AOADMM.m:707, :1016), where B is the R x R system matrix of one mode.
+__global__ __launch_bounds__(64) void sym_eig_small_k(const double* B, int n, double* w, double* V) {
+  extern __shared__ double sh[];          // A[n*n], Q[n*n]
+  __shared__ double cs[2];
+  __shared__ int done;
+  double* A = sh;
+  double* Q = sh + n * n;
+  const int t = threadIdx.x;
+  for (int e = t; e < n * n; e += 64) { A[e] = B[e]; Q[e] = (e % n == e / n) ? 1.0 : 0.0; }
+  __syncthreads();
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    if (t == 0) {
+      double off = 0.0, tot = 0.0;
+      for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) { const double v = A[i + n * j]; tot += v * v; if (i != j) off += v * v; }
+      done = !(off > 1e-30 * tot);
+    }
+    __syncthreads();
+    if (done) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        if (t == 0) {
+          const double apq = A[p + n * q];
+          double c = 1.0, s = 0.0;
+          if (apq != 0.0) {
+            const double theta = (A[q + n * q] - A[p + n * p]) / (2.0 * apq);
+            const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            c = 1.0 / sqrt(tt * tt + 1.0);
+            s = tt * c;
+          }
+          cs[0] = c; cs[1] = s;
+        }
+        __syncthreads();
+        const double c = cs[0], s = cs[1];
+        if (s != 0.0 && t < n) {                     // columns p, q of A and of Q (thread = row)
+          const double akp = A[t + n * p], akq = A[t + n * q];
+          A[t + n * p] = c * akp - s * akq;
+          A[t + n * q] = s * akp + c * akq;
+          const double qkp = Q[t + n * p], qkq = Q[t + n * q];
+          Q[t + n * p] = c * qkp - s * qkq;
+          Q[t + n * q] = s * qkp + c * qkq;
+        }
+        __syncthreads();
+        if (s != 0.0 && t < n) {                     // rows p, q of A (thread = column)
+          const double apk = A[p + n * t], aqk = A[q + n * t];
+          A[p + n * t] = c * apk - s * aqk;
+          A[q + n * t] = s * apk + c * aqk;
+        }
+        __syncthreads();
+      }
+  }
+  for (int e = t; e < n * n; e += 64) V[e] = Q[e];
+  if (t < n) w[t] = A[t + n * t];
+}
+void sym_eig_small(const double* B, int n, double* w, double* V, hipStream_t s) {
+  AO_REQUIRE(n >= 1 && n <= kMaxRank, "sym_eig_small: n out of range");
+  sym_eig_small_k<<<1, 64, (size_t)2 * n * n * sizeof(double), s>>>(B, n, w, V);
+  AO_KERNEL_CHECK();
+}
+
+// X = AA \ BB for a symmetric positive definite AA (q x q, overwritten by its Cholesky factor) and nrhs
+// right-hand sides (BB, q x nrhs, overwritten by X): the Delta update of coupling type 3 (:839).  One
+// workgroup, matrix in global memory; q is the row count of Delta (tens to hundreds).
+__global__ __launch_bounds__(256) void spd_solve_left_k(double* AA, int64_t q, double* BB, int nrhs, AdmmCtl* ctl) {
+  if (ctl && ctl->active == 0) return;
+  __shared__ double djj;
+  __shared__ int bad;
+  const int t = threadIdx.x;
+  if (t == 0) bad = 0;
+  __syncthreads();
+  for (int64_t j = 0; j < q; ++j) {
+    if (t == 0) {
+      const double d = AA[j + q * j];
+      if (!(d > 0.0)) bad = 1;
+      djj = sqrt(d);
+      AA[j + q * j] = djj;
+    }
+    __syncthreads();
+    if (bad) { if (t == 0 && ctl) ctl->notpd = 1; return; }
+    for (int64_t i = j + 1 + t; i < q; i += 256) AA[i + q * j] /= djj;
+    __syncthreads();
+    for (int64_t k = j + 1; k < q; ++k) {            // column k of the trailing block, rows k..q-1
+      const double lkj = AA[k + q * j];
+      for (int64_t i = k + t; i < q; i += 256) AA[i + q * k] -= AA[i + q * j] * lkj;
+    }
+    __syncthreads();
+  }
+  for (int r = t; r < nrhs; r += 256) {               // one right-hand side per thread
+    double* x = BB + q * r;
+    for (int64_t i = 0; i < q; ++i) {
+      double v = x[i];
+      for (int64_t k = 0; k < i; ++k) v -= AA[i + q * k] * x[k];
+      x[i] = v / AA[i + q * i];
+    }
+    for (int64_t i = q - 1; i >= 0; --i) {
+      double v = x[i];
+      for (int64_t k = i + 1; k < q; ++k) v -= AA[k + q * i] * x[k];
+      x[i] = v / AA[i + q * i];
+    }
+  }
+}
+void spd_solve_left(double* AA, int64_t q, double* BB, int nrhs, AdmmCtl* ctl, hipStream_t s) {
+  spd_solve_left_k<<<1, 256, 0, s>>>(AA, q, BB, nrhs, ctl);
+  AO_KERNEL_CHECK();
+}
+
+// W(i,j) /= (scale_row * lam[i] + shift + mu[j])   (Sylvester solve in the two eigenbases)
+__global__ void sylv_scale_k(double* W, int64_t rows, int R, const double* lam, const double* mu, const double* rho,
+                             double lam_mul, double shift_mul, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  const double r2 = rho[0] / 2;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < rows * R; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e % rows;
+    const int j = (int)(e / rows);
+    W[e] = W[e] / (r2 * lam_mul * lam[i] + r2 * shift_mul + mu[j]);
+  }
+}
+void sylv_scale(double* W, int64_t rows, int R, const double* lam, const double* mu, const double* rho, double lam_mul,
+                double shift_mul, const AdmmCtl* ctl, hipStream_t s) {
+  int64_t nb = cdiv(rows * R, 256);
+  if (nb > 1024) nb = 1024;
+  sylv_scale_k<<<(unsigned)nb, 256, 0, s>>>(W, rows, R, lam, mu, rho, lam_mul, shift_mul, ctl);
   AO_KERNEL_CHECK();
 }
 

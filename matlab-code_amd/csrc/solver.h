@@ -53,7 +53,12 @@ struct ModeInfo {
   int coupling = -1;
   bool constrained = false;
   ProxSpec prox;
-  DevBuf H, H2;
+  DevBuf H, H2, Ht, H2t;   // coupling transformation matrices and their transposes
+  DevBuf HHt;              // coupling type 2: H*H' (R x R)
+  DevBuf eU, eUt, eLam;    // coupling types 1/5: H'*H = eU diag(eLam) eU' (rows x rows, host Jacobi once per model)
+  DevBuf eV, eMu;          // coupling types 1/5: eigendecomposition of the R x R system matrix (every outer iteration)
+  std::vector<double> H_host;
+  int64_t img_rows = 0, img_cols = 0;   // shape of the factor-side coupling image (= shape of coupling_dual_fac)
   QuadPrep quad;           // quadratic regularization: L and its eigendecomposition
   int64_t hr = 0, hc = 0, h2r = 0, h2c = 0;
   double ridge = 0.0;
@@ -62,7 +67,7 @@ struct ModeInfo {
   int64_t muD_rows = 0, muD_cols = 0;
   uint64_t version = 1;
   // work buffers
-  DevBuf A, Ab, gram, C, Bsys, L, Binv, rho, Zold, V, Znew, part, proxws, RHS, TD, tmp;
+  DevBuf A, Ab, gram, C, Bsys, L, Binv, rho, Zold, V, Znew, part, proxws, RHS, TD, TF, tmp, W1, W2;
   const double* Aeff = nullptr;
 };
 

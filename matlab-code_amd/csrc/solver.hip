@@ -3,6 +3,7 @@
 // cases 0 and 4), :1213-1363 (objective), functions/evaluate_stopping_conditions.m.
 #include "solver.h"
 #include "em.h"
+#include "hosteig.h"
 
 #include <rccl/rccl.h>
 
@@ -156,6 +157,14 @@ static void upload_small(DevBuf& b, const double* host, int64_t n, hipStream_t s
   AO_HIP(hipStreamSynchronize(s));
 }
 
+static void upload_with_transpose(DevBuf& b, DevBuf& bt, const double* host, int64_t r, int64_t c, hipStream_t s) {
+  std::vector<double> t((size_t)r * c);
+  for (int64_t j = 0; j < c; ++j)
+    for (int64_t i = 0; i < r; ++i) t[(size_t)j + (size_t)c * i] = host[(size_t)i + (size_t)r * j];
+  upload_small(b, host, r * c, s);
+  upload_small(bt, t.data(), r * c, s);
+}
+
 void Engine::set_coupling(int mode, int coupling, const double* H, int64_t hr, int64_t hc, const double* H2,
                           int64_t h2r, int64_t h2c) {
   check_mode(mode);
@@ -163,8 +172,13 @@ void Engine::set_coupling(int mode, int coupling, const double* H, int64_t hr, i
   ModeInfo& mi = modes_[mode];
   mi.coupling = coupling;
   mi.hr = mi.hc = mi.h2r = mi.h2c = 0;
-  if (H && hr > 0 && hc > 0) { upload_small(mi.H, H, hr * hc, stream_); mi.hr = hr; mi.hc = hc; }
-  if (H2 && h2r > 0 && h2c > 0) { upload_small(mi.H2, H2, h2r * h2c, stream_); mi.h2r = h2r; mi.h2c = h2c; }
+  mi.H_host.clear();
+  if (H && hr > 0 && hc > 0) {
+    upload_with_transpose(mi.H, mi.Ht, H, hr, hc, stream_);
+    mi.hr = hr; mi.hc = hc;
+    mi.H_host.assign(H, H + (size_t)hr * hc);
+  }
+  if (H2 && h2r > 0 && h2c > 0) { upload_with_transpose(mi.H2, mi.H2t, H2, h2r, h2c, stream_); mi.h2r = h2r; mi.h2c = h2c; }
 }
 
 void Engine::set_coupling_type(int coupling, int type) {
@@ -208,22 +222,105 @@ void Engine::model_end() {
     AO_REQUIRE(!ci.modes.empty(), "coupling %d couples no mode", c);
     AO_REQUIRE(ci.modes.size() <= 8, "more than 8 modes in one coupling");
     const ModeInfo& m0 = modes_[ci.modes[0]];
-    if (ci.type == 0) {                       // check_data_input.m:48-61
-      ci.rows = m0.rows; ci.cols = m0.R;
-      for (int m : ci.modes) {
-        AO_REQUIRE(modes_[m].rows == m0.rows, "Coupled factor matrices of mode %d and mode %d need to have same number of rows.", ci.modes[0] + 1, m + 1);
-        AO_REQUIRE(modes_[m].R == m0.R, "Coupled factor matrices of mode %d and mode %d need to have same number of components/columns.", ci.modes[0] + 1, m + 1);
+    auto need_H = [&](int m) { AO_REQUIRE(modes_[m].hr > 0, "Coupling matrix for mode %d is missing.", m + 1); };
+    switch (ci.type) {
+      case 0:                                   // C = Delta  (check_data_input.m:48-61)
+        ci.rows = m0.rows; ci.cols = m0.R;
+        for (int m : ci.modes) {
+          AO_REQUIRE(modes_[m].rows == m0.rows, "Coupled factor matrices of mode %d and mode %d need to have same number of rows.", ci.modes[0] + 1, m + 1);
+          AO_REQUIRE(modes_[m].R == m0.R, "Coupled factor matrices of mode %d and mode %d need to have same number of components/columns.", ci.modes[0] + 1, m + 1);
+          modes_[m].img_rows = modes_[m].rows; modes_[m].img_cols = modes_[m].R;
+        }
+        break;
+      case 1:                                   // H*C = Delta : H is (rows_Delta x rows_m)  (:62-80)
+        need_H(ci.modes[0]);
+        ci.rows = m0.hr; ci.cols = m0.R;
+        for (int m : ci.modes) {
+          need_H(m);
+          AO_REQUIRE(modes_[m].hc == modes_[m].rows, "Mismatch between sz and number of columns of coupling matrix for mode %d.", m + 1);
+          AO_REQUIRE(modes_[m].hr == ci.rows, "Coupling transformation matrices need to have same number of rows for mode %d and mode %d.", ci.modes[0] + 1, m + 1);
+          AO_REQUIRE(modes_[m].R == m0.R, "Coupled factor matrices of mode %d and mode %d need to have same number of components/columns.", ci.modes[0] + 1, m + 1);
+          modes_[m].img_rows = ci.rows; modes_[m].img_cols = modes_[m].R;
+        }
+        break;
+      case 2:                                   // C*H = Delta : H is (R_m x cols_Delta)  (:81-98)
+        need_H(ci.modes[0]);
+        ci.rows = m0.rows; ci.cols = m0.hc;
+        for (int m : ci.modes) {
+          need_H(m);
+          AO_REQUIRE(modes_[m].hr == modes_[m].R, "Mismatch between number of components and number of rows of coupling matrix for mode %d.", m + 1);
+          AO_REQUIRE(modes_[m].hc == ci.cols, "Coupling transformation matrices need to have same number of columns for mode %d and mode %d.", ci.modes[0] + 1, m + 1);
+          AO_REQUIRE(modes_[m].rows == ci.rows, "Coupled factor matrices of mode %d and mode %d need to have same number of rows.", ci.modes[0] + 1, m + 1);
+          modes_[m].img_rows = ci.rows; modes_[m].img_cols = ci.cols;
+        }
+        AO_REQUIRE(ci.cols <= kMaxRank, "coupling type 2: Delta has more than %d columns", kMaxRank);
+        break;
+      case 3:                                   // C = H*Delta : H is (rows_m x rows_Delta)  (:99-114)
+        need_H(ci.modes[0]);
+        ci.rows = m0.hc; ci.cols = m0.R;
+        for (int m : ci.modes) {
+          need_H(m);
+          AO_REQUIRE(modes_[m].hr == modes_[m].rows, "Mismatch between sz and number of rows of coupling matrix for mode %d.", m + 1);
+          AO_REQUIRE(modes_[m].hc == ci.rows, "Coupling transformation matrices need to have same number of columns for mode %d and mode %d.", ci.modes[0] + 1, m + 1);
+          AO_REQUIRE(modes_[m].R == m0.R, "Coupled factor matrices of mode %d and mode %d need to have same number of components/columns.", ci.modes[0] + 1, m + 1);
+          modes_[m].img_rows = modes_[m].rows; modes_[m].img_cols = modes_[m].R;
+        }
+        break;
+      case 4:                                   // C = Delta*H : H is (cols_Delta x R_m)
+        need_H(ci.modes[0]);
+        ci.rows = m0.rows; ci.cols = m0.hr;
+        for (int m : ci.modes) {
+          need_H(m);
+          AO_REQUIRE(modes_[m].rows == ci.rows && modes_[m].hr == ci.cols && modes_[m].hc == modes_[m].R,
+                     "coupling type 4: transformation matrix of mode %d has the wrong shape", m + 1);
+          modes_[m].img_rows = modes_[m].rows; modes_[m].img_cols = modes_[m].R;
+        }
+        AO_REQUIRE(ci.cols <= kMaxRank, "coupling type 4: Delta has more than %d columns", kMaxRank);
+        break;
+      default:                                  // 5: H*C = Delta*H2 : H (rows_Delta x rows_m), H2 (cols_Delta x R_m)  (:125-140)
+        need_H(ci.modes[0]);
+        AO_REQUIRE(m0.h2r > 0, "Coupling matrix H2 for mode %d is missing.", ci.modes[0] + 1);
+        ci.rows = m0.hr; ci.cols = m0.h2r;
+        for (int m : ci.modes) {
+          need_H(m);
+          AO_REQUIRE(modes_[m].h2r > 0, "Coupling matrix H2 for mode %d is missing.", m + 1);
+          AO_REQUIRE(modes_[m].hc == modes_[m].rows && modes_[m].hr == ci.rows && modes_[m].h2r == ci.cols &&
+                     modes_[m].h2c == modes_[m].R, "coupling type 5: transformation matrices of mode %d have the wrong shape", m + 1);
+          modes_[m].img_rows = ci.rows; modes_[m].img_cols = modes_[m].R;
+        }
+        AO_REQUIRE(ci.cols <= kMaxRank, "coupling type 5: Delta has more than %d columns", kMaxRank);
+        break;
+    }
+    for (int m : ci.modes) {
+      ModeInfo& mi = modes_[m];
+      if (ci.type == 2) {                       // H*H' (R x R) for the system matrix (:314)
+        std::vector<double> hh((size_t)mi.R * mi.R, 0.0);
+        for (int a = 0; a < mi.R; ++a)
+          for (int b2 = 0; b2 < mi.R; ++b2) {
+            double acc = 0.0;
+            for (int64_t c2 = 0; c2 < mi.hc; ++c2) acc += mi.H_host[(size_t)a + (size_t)mi.hr * c2] * mi.H_host[(size_t)b2 + (size_t)mi.hr * c2];
+            hh[(size_t)a + (size_t)mi.R * b2] = acc;
+          }
+        upload_small(mi.HHt, hh.data(), (int64_t)mi.R * mi.R, stream_);
       }
-    } else if (ci.type == 4) {                // C = Delta*H : H is (cols x R_m)
-      AO_REQUIRE(m0.hr > 0, "Coupling matrix for mode %d is missing.", ci.modes[0] + 1);
-      ci.rows = m0.rows; ci.cols = m0.hr;
-      for (int m : ci.modes) {
-        AO_REQUIRE(modes_[m].hr > 0, "Coupling matrix for mode %d is missing.", m + 1);
-        AO_REQUIRE(modes_[m].rows == ci.rows && modes_[m].hr == ci.cols && modes_[m].hc == modes_[m].R,
-                   "coupling type 4: transformation matrix of mode %d has the wrong shape", m + 1);
+      if (ci.type == 1 || ci.type == 5) {       // H'*H = U diag(lam) U' once: the Sylvester solves reuse it (:288, :377)
+        const int64_t n = mi.rows;
+        if (n > 4096) throw Error(AOADMM_ERR_UNSUPPORTED, "coupling types 1/5: modes beyond 4096 rows are not diagonalised on the host");
+        std::vector<double> hth((size_t)n * n, 0.0), lam, U;
+        for (int64_t a = 0; a < n; ++a)
+          for (int64_t b2 = a; b2 < n; ++b2) {
+            double acc = 0.0;
+            for (int64_t q = 0; q < mi.hr; ++q) acc += mi.H_host[(size_t)q + (size_t)mi.hr * a] * mi.H_host[(size_t)q + (size_t)mi.hr * b2];
+            hth[(size_t)a + (size_t)n * b2] = acc; hth[(size_t)b2 + (size_t)n * a] = acc;
+          }
+        AO_REQUIRE(host_sym_eig(n, hth, lam, U) >= 0, "eigendecomposition of H'*H (mode %d) did not converge", m + 1);
+        std::vector<double> Ut((size_t)n * n);
+        for (int64_t j = 0; j < n; ++j)
+          for (int64_t i = 0; i < n; ++i) Ut[(size_t)j + (size_t)n * i] = U[(size_t)i + (size_t)n * j];
+        upload_small(mi.eU, U.data(), n * n, stream_);
+        upload_small(mi.eUt, Ut.data(), n * n, stream_);
+        upload_small(mi.eLam, lam.data(), n, stream_);
       }
-    } else {
-      throw Error(AOADMM_ERR_UNSUPPORTED, fmt("coupling type %d is not in the device path yet (use the MATLAB path)", ci.type));
     }
   }
   ctls_.alloc((size_t)(n_modes_ + n_couplings_ + 1) * sizeof(AdmmCtl));
@@ -824,7 +921,13 @@ void Engine::prepare_mode_system(int m, int nrho, const aoadmm_options& opt) {
   sb.C = mi.C.d(); sb.rho = mi.rho.d(); sb.Bsys = mi.Bsys.d(); sb.L = mi.L.d();
   sb.Binv = nrho > 0 ? mi.Binv.d() : nullptr;
   sb.ctl = ctl_of_mode(m);
+  const int cty = mi.coupling >= 0 ? couplings_[mi.coupling].type : -1;
+  if (cty == 2) sb.Madd = mi.HHt.d();
   sys_build(sb, stream_);
+  if (cty == 1 || cty == 5) {                       // B = V diag(mu) V' for the Sylvester solve of the inner loop
+    mi.eV.ensure((size_t)mi.R * mi.R * sizeof(double)); mi.eMu.ensure((size_t)mi.R * sizeof(double));
+    sym_eig_small(mi.Bsys.d(), mi.R, mi.eMu.d(), mi.eV.d(), stream_);
+  }
   t.last_pos = mi.pos;                                                        // :121-123
   mi.Aeff = mi.A.d();
   if (opt.bsum) {                                                             // :124-127
@@ -854,16 +957,47 @@ void Engine::update_uncoupled_cp_mode(int m, const aoadmm_options& opt) {
   mi.version++;
 }
 
-// T(Delta) for mode m: Delta (type 0) or Delta*H_m (type 4) into `dst`
-static void coupling_image(double* dst, const CouplingInfo& ci, const double* Delta, const ModeInfo& mi,
-                           const AdmmCtl* ctl, hipStream_t s) {
-  if (ci.type == 0) {
-    Coef c[1] = {coef(1.0)};
-    const double* x[1] = {Delta};
-    ew_lincomb(dst, ci.rows * ci.cols, 1, c, x, ctl, s);
-  } else {
-    gemm_small(dst, mi.rows, Delta, ci.rows, mi.H.d(), mi.hr, ci.rows, (int)ci.cols, mi.R, 0, coef(1.0), 0.0, ctl, s);
+// The six linear couplings (cmtf_fun_AOADMM.m:625-1075) in one form:  Tf_m(C_m) = Sd_m(Delta)
+//   type 0: C = Delta | 1: H*C = Delta | 2: C*H = Delta | 3: C = H*Delta | 4: C = Delta*H | 5: H*C = Delta*H2
+// Sd: the Delta-side image for mode m (shape img_rows x img_cols)
+static void image_d(double* dst, const CouplingInfo& ci, const double* D, const ModeInfo& mi, const AdmmCtl* ctl,
+                    hipStream_t s) {
+  switch (ci.type) {
+    case 3: gemm_small(dst, mi.rows, mi.H.d(), mi.hr, D, ci.rows, mi.rows, (int)ci.rows, mi.R, 0, coef(1.0), 0.0, ctl, s); break;
+    case 4: gemm_small(dst, mi.rows, D, ci.rows, mi.H.d(), mi.hr, ci.rows, (int)ci.cols, mi.R, 0, coef(1.0), 0.0, ctl, s); break;
+    case 5: gemm_small(dst, ci.rows, D, ci.rows, mi.H2.d(), mi.h2r, ci.rows, (int)ci.cols, mi.R, 0, coef(1.0), 0.0, ctl, s); break;
+    default: {
+      Coef c[1] = {coef(1.0)};
+      const double* x[1] = {D};
+      ew_lincomb(dst, ci.rows * ci.cols, 1, c, x, ctl, s);
+    }
   }
+}
+// Tf: the factor-side image (same shape); types 0, 3, 4 are the identity and return F itself
+static const double* image_f(double* dst, const CouplingInfo& ci, const double* F, const ModeInfo& mi,
+                             const AdmmCtl* ctl, hipStream_t s) {
+  if (ci.type == 1 || ci.type == 5) {
+    gemm_small(dst, mi.hr, mi.H.d(), mi.hr, F, mi.rows, mi.hr, (int)mi.rows, mi.R, 0, coef(1.0), 0.0, ctl, s);
+    return dst;
+  }
+  if (ci.type == 2) {
+    gemm_small(dst, mi.rows, F, mi.rows, mi.H.d(), mi.hr, mi.rows, mi.R, (int)mi.hc, 0, coef(1.0), 0.0, ctl, s);
+    return dst;
+  }
+  return F;
+}
+// Tf': adjoint of the factor-side map applied to Y (img shape) -> rows x R ; identity for types 0, 3, 4
+static const double* adjoint_f(double* dst, const CouplingInfo& ci, const double* Y, const ModeInfo& mi,
+                               const AdmmCtl* ctl, hipStream_t s) {
+  if (ci.type == 1 || ci.type == 5) {               // H' * Y
+    gemm_small(dst, mi.rows, mi.Ht.d(), mi.hc, Y, mi.img_rows, mi.rows, (int)mi.hr, mi.R, 0, coef(1.0), 0.0, ctl, s);
+    return dst;
+  }
+  if (ci.type == 2) {                                // Y * H'
+    gemm_small(dst, mi.rows, Y, mi.rows, mi.H.d(), mi.hr, mi.rows, (int)mi.hc, mi.R, 1, coef(1.0), 0.0, ctl, s);
+    return dst;
+  }
+  return Y;
 }
 
 __global__ void coupling_coefs_k(double* coef, const double* const* rhos, int n) {
@@ -878,7 +1012,7 @@ __global__ void coupling_coefs_k(double* coef, const double* const* rhos, int n)
 
 struct AAArgs { const double* H[8]; const double* rho[8]; int R[8]; int n; int Rc; };
 __global__ void coupling_AA_k(double* AA, AAArgs a) {
-  // AA = sum_j rho_j * H_j * H_j'   (:941-954)
+  // AA = sum_j rho_j * H_j * H_j'   (:941-954 ; :1033-1047 with H2 and the common rhoC)
   const int Rc = a.Rc;
   for (int e = threadIdx.x; e < Rc * Rc; e += blockDim.x) {
     const int i = e % Rc, k = e / Rc;
@@ -896,11 +1030,18 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
   CouplingInfo& ci = couplings_[c];
   AdmmCtl* ctl = ctl_of_coupling(c);
   const int n = (int)ci.modes.size();
+  const int ty = ci.type;
   const int64_t nD = ci.rows * ci.cols;
   ci.DeltaOld.ensure(nD * 8); ci.BB.ensure(nD * 8); ci.dD.ensure(nD * 8); ci.tmp.ensure(nD * 8);
   ci.coef.ensure(64 * 8);
-  ci.AA.ensure((size_t)ci.cols * ci.cols * 8); ci.LAA.ensure((size_t)ci.cols * ci.cols * 8);
+  const int64_t qa = ty == 3 ? ci.rows : ci.cols;    // order of the Delta normal equations (types 3 / 4, 5)
+  ci.AA.ensure((size_t)qa * qa * 8); ci.LAA.ensure((size_t)qa * qa * 8);
   double* resid = slots_.d() + n_modes_ * kSlotsPerMode + 2 * n_tensors_;
+  for (int j = 0; j < n; ++j) {                       // image-shaped work buffers
+    ModeInfo& mi = modes_[ci.modes[j]];
+    const size_t nimg = (size_t)std::max(mi.rows * mi.R, mi.img_rows * mi.img_cols) * sizeof(double);
+    mi.TD.ensure(nimg); mi.TF.ensure(nimg); mi.tmp.ensure(nimg); mi.W1.ensure(nimg); mi.W2.ensure(nimg);
+  }
   // reset the loop control (the per-mode sys_build calls reset their own blocks)
   ctl_reset(ctl, stream_);
   // per-outer-iteration constants
@@ -909,26 +1050,53 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
   for (int j = 0; j < n; ++j) hp[j] = modes_[ci.modes[j]].rho.d();
   rho_ptrs.alloc(n * sizeof(double*));
   AO_HIP(hipMemcpyAsync(rho_ptrs.p, hp.data(), n * sizeof(double*), hipMemcpyHostToDevice, stream_));
-  if (ci.type == 0) {
+  const double* rho_last = hp[n - 1];                 // type 5: rhoC = mean(rho{mm}) with the stale loop variable (:1032)
+  if (ty == 0 || ty == 1 || ty == 2) {
     coupling_coefs_k<<<1, 64, 0, stream_>>>(ci.coef.d(), rho_ptrs.as<const double*>(), n);
     AO_KERNEL_CHECK();
-  } else {
+  } else if (ty == 4 || ty == 5) {
     AAArgs aa;
     aa.n = n; aa.Rc = (int)ci.cols;
-    for (int j = 0; j < n; ++j) { aa.H[j] = modes_[ci.modes[j]].H.d(); aa.rho[j] = hp[j]; aa.R[j] = modes_[ci.modes[j]].R; }
+    for (int j = 0; j < n; ++j) {
+      const ModeInfo& mj = modes_[ci.modes[j]];
+      aa.H[j] = ty == 4 ? mj.H.d() : mj.H2.d();
+      aa.rho[j] = ty == 4 ? hp[j] : rho_last;
+      aa.R[j] = mj.R;
+    }
     coupling_AA_k<<<1, 256, 0, stream_>>>(ci.AA.d(), aa);
     AO_KERNEL_CHECK();
     chol_only(ci.LAA.d(), ci.AA.d(), (int)ci.cols, ctl, stream_);
   }
   for (int it = 0; it < opt.MaxInnerIters; ++it) {
-    // ---- primal updates (:635-658 / :913-936)
+    // ---- primal updates (:635-658, :713-730, :783-800, :853-870, :913-936, :1004-1020)
     for (int j = 0; j < n; ++j) {
       ModeInfo& mi = modes_[ci.modes[j]];
-      coupling_image(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_);
-      Coef cf[5] = {coef(1.0), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), -0.5), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), -0.5)};
-      const double* x[5] = {mi.Aeff, mi.TD.d(), mi.muD.d(), mi.Z.d(), mi.mu.d()};
-      ew_lincomb(mi.RHS.d(), mi.rows * mi.R, mi.constrained ? 5 : 3, cf, x, ctl, stream_);
-      row_solve(mi.fac.d(), mi.rows, mi.RHS.d(), mi.rows, mi.L.d(), mi.rows, mi.R, ctl, stream_);
+      const int64_t nm = mi.rows * mi.R, ni = mi.img_rows * mi.img_cols;
+      image_d(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_);
+      if (ty == 0 || ty == 3 || ty == 4) {
+        Coef cf[5] = {coef(1.0), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), -0.5), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), -0.5)};
+        const double* x[5] = {mi.Aeff, mi.TD.d(), mi.muD.d(), mi.Z.d(), mi.mu.d()};
+        ew_lincomb(mi.RHS.d(), nm, mi.constrained ? 5 : 3, cf, x, ctl, stream_);
+      } else {
+        Coef c2[2] = {coef(1.0), coef(-1.0)};
+        const double* x2[2] = {mi.TD.d(), mi.muD.d()};
+        ew_lincomb(mi.tmp.d(), ni, 2, c2, x2, ctl, stream_);                   // Sd(Delta) - mu_Delta
+        const double* adj = adjoint_f(mi.TF.d(), ci, mi.tmp.d(), mi, ctl, stream_);
+        Coef cf[4] = {coef(1.0), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), -0.5)};
+        const double* x[4] = {mi.Aeff, adj, mi.Z.d(), mi.mu.d()};
+        ew_lincomb(mi.RHS.d(), nm, mi.constrained ? 4 : 2, cf, x, ctl, stream_);
+      }
+      if (ty == 1 || ty == 5) {
+        // sylvester(B2, B, A_inner) (:707, :1016) with B2 = rho/2*H'H (+ rho/2*I if constrained) = U (..) U',
+        // B = V diag(mu) V':  X = U * ((U' A_inner V) ./ (beta_i + mu_j)) * V'
+        gemm_small(mi.W1.d(), mi.rows, mi.eUt.d(), mi.rows, mi.RHS.d(), mi.rows, mi.rows, (int)mi.rows, mi.R, 0, coef(1.0), 0.0, ctl, stream_);
+        gemm_small(mi.W2.d(), mi.rows, mi.W1.d(), mi.rows, mi.eV.d(), mi.R, mi.rows, mi.R, mi.R, 0, coef(1.0), 0.0, ctl, stream_);
+        sylv_scale(mi.W2.d(), mi.rows, mi.R, mi.eLam.d(), mi.eMu.d(), mi.rho.d(), 1.0, mi.constrained ? 1.0 : 0.0, ctl, stream_);
+        gemm_small(mi.W1.d(), mi.rows, mi.W2.d(), mi.rows, mi.eV.d(), mi.R, mi.rows, mi.R, mi.R, 1, coef(1.0), 0.0, ctl, stream_);
+        gemm_small(mi.fac.d(), mi.rows, mi.eU.d(), mi.rows, mi.W1.d(), mi.rows, mi.rows, (int)mi.rows, mi.R, 0, coef(1.0), 0.0, ctl, stream_);
+      } else {
+        row_solve(mi.fac.d(), mi.rows, mi.RHS.d(), mi.rows, mi.L.d(), mi.rows, mi.R, ctl, stream_);
+      }
     }
     // ---- Delta update
     {
@@ -936,37 +1104,58 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
       const double* x1[1] = {ci.Delta.d()};
       ew_lincomb(ci.DeltaOld.d(), nD, 1, c1, x1, ctl, stream_);
     }
-    if (ci.type == 0) {
+    if (ty == 0 || ty == 1 || ty == 2) {              // weighted mean of Tf(C_j) + mu_j (:661-675, :735-741, :805-811)
       for (int j = 0; j < n; ++j) {
         ModeInfo& mi = modes_[ci.modes[j]];
+        const double* tf = image_f(mi.TF.d(), ci, mi.fac.d(), mi, ctl, stream_);
         if (j == 0) {
           Coef cf[2] = {coef(ci.coef.d() + j, 1.0), coef(ci.coef.d() + j, 1.0)};
-          const double* x[2] = {mi.fac.d(), mi.muD.d()};
+          const double* x[2] = {tf, mi.muD.d()};
           ew_lincomb(ci.Delta.d(), nD, 2, cf, x, ctl, stream_);
         } else {
           Coef cf[3] = {coef(1.0), coef(ci.coef.d() + j, 1.0), coef(ci.coef.d() + j, 1.0)};
-          const double* x[3] = {ci.Delta.d(), mi.fac.d(), mi.muD.d()};
+          const double* x[3] = {ci.Delta.d(), tf, mi.muD.d()};
           ew_lincomb(ci.Delta.d(), nD, 3, cf, x, ctl, stream_);
         }
       }
-    } else {
+    } else if (ty == 3) {                             // Delta = AA \ BB (:875-885)
       for (int j = 0; j < n; ++j) {
         ModeInfo& mi = modes_[ci.modes[j]];
         Coef cf[2] = {coef(1.0), coef(1.0)};
         const double* x[2] = {mi.fac.d(), mi.muD.d()};
         ew_lincomb(mi.tmp.d(), mi.rows * mi.R, 2, cf, x, ctl, stream_);
-        // BB += rho_j * (fac+mu) * H_j'   (:955)
-        gemm_small(ci.BB.d(), ci.rows, mi.tmp.d(), mi.rows, mi.H.d(), mi.hr, ci.rows, mi.R, (int)ci.cols, 1,
+        gemm_small(ci.AA.d(), ci.rows, mi.Ht.d(), mi.hc, mi.H.d(), mi.hr, ci.rows, (int)mi.rows, (int)ci.rows, 0,
+                   coef(mi.rho.d(), 1.0), j == 0 ? 0.0 : 1.0, ctl, stream_);
+        gemm_small(ci.BB.d(), ci.rows, mi.Ht.d(), mi.hc, mi.tmp.d(), mi.rows, ci.rows, (int)mi.rows, mi.R, 0,
                    coef(mi.rho.d(), 1.0), j == 0 ? 0.0 : 1.0, ctl, stream_);
       }
-      row_solve(ci.Delta.d(), ci.rows, ci.BB.d(), ci.rows, ci.LAA.d(), ci.rows, (int)ci.cols, ctl, stream_);  // BB/AA (:962)
+      spd_solve_left(ci.AA.d(), ci.rows, ci.BB.d(), (int)ci.cols, ctl, stream_);
+      Coef c1[1] = {coef(1.0)};
+      const double* x1[1] = {ci.BB.d()};
+      ew_lincomb(ci.Delta.d(), nD, 1, c1, x1, ctl, stream_);
+    } else {                                          // types 4, 5: Delta = BB / AA (:939-963, :1026-1054)
+      for (int j = 0; j < n; ++j) {
+        ModeInfo& mi = modes_[ci.modes[j]];
+        const double* tf = image_f(mi.TF.d(), ci, mi.fac.d(), mi, ctl, stream_);
+        Coef cf[2] = {coef(1.0), coef(1.0)};
+        const double* x[2] = {tf, mi.muD.d()};
+        ew_lincomb(mi.tmp.d(), mi.img_rows * mi.img_cols, 2, cf, x, ctl, stream_);
+        // BB += rho_j * (Tf(C_j) + mu_j) * H_j'   (:955 ; :1048 with H2 and rhoC)
+        if (ty == 4)
+          gemm_small(ci.BB.d(), ci.rows, mi.tmp.d(), mi.rows, mi.H.d(), mi.hr, ci.rows, mi.R, (int)ci.cols, 1,
+                     coef(mi.rho.d(), 1.0), j == 0 ? 0.0 : 1.0, ctl, stream_);
+        else
+          gemm_small(ci.BB.d(), ci.rows, mi.tmp.d(), mi.img_rows, mi.H2.d(), mi.h2r, ci.rows, mi.R, (int)ci.cols, 1,
+                     coef(rho_last, 1.0), j == 0 ? 0.0 : 1.0, ctl, stream_);
+      }
+      row_solve(ci.Delta.d(), ci.rows, ci.BB.d(), ci.rows, ci.LAA.d(), ci.rows, (int)ci.cols, ctl, stream_);
     }
     {
       Coef cf[2] = {coef(1.0), coef(-1.0)};
       const double* x[2] = {ci.Delta.d(), ci.DeltaOld.d()};
       ew_lincomb(ci.dD.d(), nD, 2, cf, x, ctl, stream_);
     }
-    // ---- duals, constraints, residual pieces (:678-692 / :966-980)
+    // ---- duals, constraints, residual pieces (:678-692 and the same block of every case)
     FinalizeArgs fa;
     fa.nmodes = n;
     fa.max_inner = opt.MaxInnerIters;
@@ -976,20 +1165,23 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
       const int m = ci.modes[j];
       ModeInfo& mi = modes_[m];
       double* sl = resid + (int64_t)m * kResidPerMode;
-      const int64_t nm = mi.rows * mi.R;
-      coupling_image(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_);
+      const int64_t nm = mi.rows * mi.R, ni = mi.img_rows * mi.img_cols;
+      image_d(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_);
+      const double* tf = image_f(mi.TF.d(), ci, mi.fac.d(), mi, ctl, stream_);
       Coef cf[3] = {coef(1.0), coef(1.0), coef(-1.0)};
-      const double* x[3] = {mi.muD.d(), mi.fac.d(), mi.TD.d()};
-      ew_lincomb(mi.muD.d(), nm, 3, cf, x, ctl, stream_);                      // mu_Delta update
+      const double* x[3] = {mi.muD.d(), tf, mi.TD.d()};
+      ew_lincomb(mi.muD.d(), ni, 3, cf, x, ctl, stream_);                      // mu_Delta += Tf(C) - Sd(Delta)
       if (mi.constrained)
         constraint_update(mi.prox, mi.fac.d(), mi.Z.d(), mi.mu.d(), mi.Zold.d(), mi.V.d(), mi.rows, mi.R,
                           mi.rho.d(), 1.0, mi.proxws.d(), sl, redws_.d(), ctl, stream_);
       else
         sumsq_diff(sl + 1, mi.fac.d(), nullptr, nm, redws_.d(), ctl, stream_);
-      sumsq_diff(sl + 4, mi.fac.d(), mi.TD.d(), nm, redws_.d(), ctl, stream_);
-      sumsq_diff(sl + 5, mi.muD.d(), nullptr, nm, redws_.d(), ctl, stream_);
-      coupling_image(mi.tmp.d(), ci, ci.dD.d(), mi, ctl, stream_);
-      sumsq_diff(sl + 6, mi.tmp.d(), nullptr, nm, redws_.d(), ctl, stream_);
+      sumsq_diff(sl + 4, tf, mi.TD.d(), ni, redws_.d(), ctl, stream_);
+      sumsq_diff(sl + 5, mi.muD.d(), nullptr, ni, redws_.d(), ctl, stream_);
+      image_d(mi.tmp.d(), ci, ci.dD.d(), mi, ctl, stream_);
+      sumsq_diff(sl + 6, mi.tmp.d(), nullptr, ni, redws_.d(), ctl, stream_);
+      // denominator of the primal coupling residual: ||H*C|| (:1125) / ||C*H|| (:1143) for types 1, 2, else ||C||
+      sumsq_diff(sl + 7, (ty == 1 || ty == 2) ? tf : mi.fac.d(), nullptr, (ty == 1 || ty == 2) ? ni : nm, redws_.d(), ctl, stream_);
       fa.slots[j] = sl;
       fa.constrained[j] = mi.constrained ? 1 : 0;
       fa.coupled[j] = 1;
@@ -1073,10 +1265,14 @@ void Engine::eval_objective_enqueue(bool first) {
         rb.add(k);
       }
     }
-    if (mi.coupling >= 0) {
+    if (mi.coupling >= 0) {                        // :1303-1329
       CouplingInfo& ci = couplings_[mi.coupling];
-      coupling_image(mi.TD.d(), ci, ci.Delta.d(), mi, nullptr, stream_);
-      add(RT_SUMSQ_DIFF, sm + 2, mi.fac.d(), mi.TD.d(), nm);
+      const size_t nimg = (size_t)std::max(nm, mi.img_rows * mi.img_cols) * sizeof(double);
+      mi.TD.ensure(nimg); mi.TF.ensure(nimg);
+      image_d(mi.TD.d(), ci, ci.Delta.d(), mi, nullptr, stream_);
+      const double* tf = image_f(mi.TF.d(), ci, mi.fac.d(), mi, nullptr, stream_);
+      add(RT_SUMSQ_DIFF, sm + 2, tf, mi.TD.d(), mi.img_rows * mi.img_cols);
+      if (tf != mi.fac.d()) add(RT_SUMSQ_DIFF, sm + 4, tf, nullptr, mi.img_rows * mi.img_cols);   // ||H*C|| / ||C*H||
     }
     if (rb.n >= kReduceBatchMax - 4) {           // many modes: flush and start the next batch
       reduce_batch(rb, redws_.d(), stream_);
@@ -1105,7 +1301,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     AO_REQUIRE(mi.has_fac, "G.fac{%d} missing", m + 1);
     if (mi.constrained) AO_REQUIRE(mi.has_Z && mi.has_mu, "G.constraint_fac{%d} / constraint_dual_fac{%d} missing", m + 1, m + 1);
     if (mi.coupling >= 0) {
-      AO_REQUIRE(mi.has_muD && mi.muD_rows == mi.rows && mi.muD_cols == mi.R, "G.coupling_dual_fac{%d} missing or mis-sized", m + 1);
+      AO_REQUIRE(mi.has_muD && mi.muD_rows == mi.img_rows && mi.muD_cols == mi.img_cols, "G.coupling_dual_fac{%d} missing or mis-sized", m + 1);
       AO_REQUIRE(couplings_[mi.coupling].has_state, "G.coupling_fac{%d} missing", mi.coupling + 1);
     }
     ensure_mode_work(mi);
@@ -1224,7 +1420,11 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
         if (g != 0.0) ++ncon;
       }
       if (has_ridge_) ft += mi.ridge * sm[0];                                  // :1297
-      if (mi.coupling >= 0) cp[mi.coupling] += std::sqrt(sm[2]) / nf;         // :1311,:1319
+      if (mi.coupling >= 0) {                                                  // :1309-1323
+        const int cty = couplings_[mi.coupling].type;
+        const double den = (cty == 1 || cty == 2 || cty == 5) ? std::sqrt(sm[4]) : nf;
+        cp[mi.coupling] += std::sqrt(sm[2]) / den;
+      }
     }
     double fc = 0.0; int nc = 0;
     for (double v : cp) { fc += v; if (v != 0.0) ++nc; }
@@ -1264,7 +1464,13 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
             if (par2 && modes_[m].pos == 1) par2_update_B(m, opt, iter);             // :191-218
             else if (par2 && modes_[m].pos == 2) par2_update_C(m, opt);              // :219-248
             else if (cid < 0) update_uncoupled_cp_mode(m, opt);
-            else prepare_mode_system(m, 1 + (modes_[m].constrained ? 1 : 0), opt);   // :269-273 / :358-362
+            else {
+              // system of a coupled mode: +rho/2*I (types 0, 3, 4: :269, :336, :358), +rho/2*H*H' (type 2, :314),
+              // nothing for the Sylvester types 1, 5 (:288-293, :377-382); +rho/2*I more if constrained
+              const int cty = couplings_[cid].type;
+              const int con = modes_[m].constrained ? 1 : 0;
+              prepare_mode_system(m, (cty == 0 || cty == 3 || cty == 4) ? 1 + con : (cty == 2 ? con : 0), opt);
+            }
           }
       if (cid >= 0) {
         coupled_admm(cid, opt);                                                // :277 / :366

@@ -151,3 +151,53 @@ def script1_model(rng, dims=(20, 30, 40), K=20, Jk=30, noise=0.0):
     distr = [lambda a, b: rng.random((a, b))] * 4 + [lambda a, b: rng.standard_normal((a, b)), lambda a, b: rng.random((a, b))]
     io = dict(lambdas_init=[[1] * R, [1] * R], nvecs=0, distr=distr, normalize=1)
     return Z, io
+
+
+def transformed_coupling_model(rng, ctype, noise=0.05):
+    """Two CP tensors whose first modes are linearly coupled with transformation matrices (coupling types 1, 2, 3, 5:
+    example_script5 / example_script13 families, scaled down): every-second-sample matrices on the row side
+    (types 1, 3, 5), partially shared components on the column side (types 2, 5)."""
+    n1, n4 = 25, 50
+    sub = np.zeros((n1, n4))
+    sub[np.arange(n1), 2 * np.arange(n1)] = 1.0                 # take every second entry (example_script5:41-45)
+    if ctype in (1, 3):
+        R1 = R4 = 3
+    else:
+        R1, R4 = 4, 3
+    D = rng.random((n4, R1))
+    if ctype in (1, 3, 5):
+        A1 = sub @ D
+        A4 = D[:, :R4]
+    else:                                                       # type 2: same rows, shared columns
+        n1 = n4 = 24
+        D = rng.random((n1, R1))
+        A1, A4 = D, D[:, :R4]
+    A = [A1, rng.standard_normal((18, R1)), rng.random((20, R1))]
+    B = [A4, rng.random((16, R4)), rng.standard_normal((14, R4))]
+    X1, X2 = full_ktensor(A), full_ktensor(B)
+    for X in (X1, X2):
+        N = rng.standard_normal(X.shape)
+        X += noise * np.linalg.norm(X) / np.linalg.norm(N) * N
+    X1 /= np.linalg.norm(X1)
+    X2 /= np.linalg.norm(X2)
+    H = [None] * 6
+    H2 = [None] * 6
+    if ctype == 1:                                              # H*C = Delta
+        H[0], H[3] = np.eye(n1), sub
+    elif ctype == 2:                                            # C*H = Delta
+        H[0], H[3] = np.vstack([np.eye(3), np.zeros((1, 3))]), np.eye(3)
+    elif ctype == 3:                                            # C = H*Delta
+        H[0], H[3] = sub, np.eye(n4)
+    else:                                                       # H*C = Delta*H2 (example_script13:43-51)
+        H[0], H[3] = np.eye(n1), sub
+        H2[0], H2[3] = np.eye(4), np.vstack([np.eye(3), np.zeros((1, 3))])
+    sz = [A[0].shape[0], 18, 20, B[0].shape[0], 16, 14]
+    Z = dict(loss_function=['Frobenius'] * 2, model=['CP', 'CP'], modes=[[1, 2, 3], [4, 5, 6]], size=sz,
+             coupling=dict(lin_coupled_modes=[1, 0, 0, 1, 0, 0], coupling_type=[ctype], coupl_trafo_matrices=H,
+                           coupl_trafo_matrices2=H2),
+             constrained_modes=[1, 0, 1, 1, 1, 0],
+             constraints=[('non-negativity',), None, ('non-negativity',), ('non-negativity',), ('non-negativity',), None],
+             weights=[0.5, 0.5], object=[X1, X2])
+    distr = [lambda a, b: rng.random((a, b))] * 6
+    io = dict(lambdas_init=[[1] * R1, [1] * R4], nvecs=0, distr=distr, normalize=1)
+    return Z, io

@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-8
 
 
-def run_both(pkg, eng, Z, io, opt, seed=7, precision='f64'):
+def run_both(pkg, eng, Z, io, opt, seed=7, precision='f64', Delta=None):
     rng = np.random.default_rng(seed)
-    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=rng)
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, Delta=Delta, rng=rng)
     _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
     _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=eng, precision=precision)
     return Fo, oo, Fg, og
@@ -278,3 +278,16 @@ def test_cp_quadratic_regularization(pkg, eng):
     got = eng.prox(('quadratic regularization', 0.02, L), x, 0.7)
     ref = np.linalg.solve(2 * 0.02 / 0.7 * L + np.eye(n), x)
     assert rel_fro(got, ref) < 1e-12
+
+
+@pytest.mark.parametrize('ctype', [1, 2, 3, 5])
+def test_transformed_couplings(pkg, eng, ctype):
+    """Coupling types 1 (H*C = Delta, example_script5), 2 (C*H = Delta), 3 (C = H*Delta) and 5 (H*C = Delta*H2,
+    example_script13): cmtf_fun_AOADMM.m:698-901, :986-1075.  Types 1/5 solve a Sylvester equation per mode (MATLAB
+    `sylvester`; here through the eigenbases of H'H and of the R x R system)."""
+    from helpers import transformed_coupling_model
+    rng = np.random.default_rng(60 + ctype)
+    Z, io = transformed_coupling_model(rng, ctype)
+    # type 5: init_coupled_AOADMM_CMTF.m:160-164 sizes coupling_fac from the Delta it is handed
+    Delta = [np.zeros((25, 4))] if ctype == 5 else None
+    compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=12), Delta=Delta))
