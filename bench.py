@@ -4,7 +4,7 @@
 Workload (BASELINE.json configs[4], the config the metric is quoted on; it fits one
 GPU): one 3-way CP block 2000 x 2000 x 2000, rank 20, mode 1 `{'TV regularization',
 0.001}`, modes 2-3 `{'non-negativity'}`, tensor stored fp32 and contracted with
-v_mfma_f32_32x32x2_f32, everything else fp64, MaxInnerIters = 5, all tolerances 0
+v_mfma_f32_16x16x4_f32 (+ packed-fp32 VALU for columns 17-20), everything else fp64, MaxInnerIters = 5, all tolerances 0
 (fixed work).  Data: synthetic, generated in HBM; init: seeded rand,
 column-normalised (init_coupled_AOADMM_CMTF.m:88-93,119-124).
 
@@ -173,7 +173,7 @@ def main():
         # HBM bytes per launch from the PMC pass committed under profiles/ (separate rocprofv3 --pmc runs,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for this exact workload
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_contract_f32.json')
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_contract16_f32.json')
         if world == 1 and args.size == 2000 and R == 20 and args.prec == 'f32' and os.path.exists(pmc):
             try:
                 traffic = float(json.load(open(pmc))['hbm_traffic_bytes_per_launch'])
@@ -193,12 +193,15 @@ def main():
             'mttkrp_mfma_frac_f32_peak': flops_mttkrp / (mttkrp_ms * 1e-3) / 1e12 / (F32_MFMA_PEAK_TF * world),
             'f_tensors_last': out['f_tensors'],
             'datagen_s': t_gen,
-            'roofline': {'bound': 'hbm', 'kernel': 'contract_%s (tensor x factor partial contraction)' % args.prec,
+            'roofline': {'bound': 'hbm', 'kernel': '%s (tensor x factor partial contraction, trailing modes)'
+                                                   % ('contract16_f32' if args.prec == 'f32' else 'contract_f64'),
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': launches,
                          'algorithmic_bytes_per_launch': bytes_per_launch,
-                         'note': 'per rank; bytes = local tensor block (s_X) + T written (8*R per unfolding row)'},
-            'second_kernel': {'kernel': 'contract_lead_f32 (leading-mode contraction, LDS-transposed; 1 of 3 tensor passes)',
+                         'note': 'per rank; algorithmic bytes = local tensor block read once (s_X per entry) + T written once '
+                                 '(s_X*R per unfolding row); traffic = FETCH_SIZE x2 + WRITE_SIZE of a separate rocprofv3 --pmc '
+                                 'run (profiles/r01_pmc_contract16_f32.json)'},
+            'second_kernel': {'kernel': 'contract_lead16_f32 (leading-mode contraction, LDS-transposed; 1 of 3 tensor passes)',
                               'launches': int(nl1.value),
                               'avg_launch_ms': (ms1.value / nl1.value) if nl1.value else None,
                               'achieved_GBps': (by1.value / nl1.value / (ms1.value / nl1.value * 1e-3) / 1e9) if nl1.value and ms1.value > 0 else None},
