@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "small.h"
+#include "loopctl.h"
 
 namespace aoadmm {
 
@@ -56,8 +57,11 @@ struct AdmmMode {
   ProxSpec prox;
 };
 int admm_partials(int64_t rows);
+// `deferred_end`: when given, the closing evaluation of the loop is not launched; the caller hands the
+// record to the next kernel it runs anyway (atb_small's `close`).
 void admm_constrained_loop(const AdmmMode& m, double* part, double* V, double* Znew, double* prox_ws,
-                           AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du, hipStream_t s);
+                           AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du, hipStream_t s,
+                           LoopEnd* deferred_end = nullptr);
 
 // generic pieces for the coupled / PARAFAC2 loops -------------------------------
 // (Z,mu) <- update_constraint (:1420-1429): Zold kept in `Zold`; slots[0..3] receive

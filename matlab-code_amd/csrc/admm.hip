@@ -3,6 +3,7 @@
 // (update_constraint), :1079-1096 (eval_res_ADMM_constr); functions/constraints_to_prox.m.
 #include "admm.h"
 #include "hosteig.h"
+#include "loopctl.h"
 
 namespace aoadmm {
 
@@ -89,35 +90,7 @@ __device__ __forceinline__ void row_solve_regs2(double (&x)[RMAX], const double*
 // evaluate eval_res_ADMM_constr (:1079-1096) + the while condition (:600).  Block 0 records the
 // outcome in ctl.  The later kernels of iteration k only look at ctl->active.
 // ---------------------------------------------------------------------------
-static constexpr int kMaxParts = 1024;     // partial-sum slots per parity
 static constexpr int kRowThreads = 64;
-
-__device__ __forceinline__ bool admm_continue(const double* part_prev, int nparts, int it, int max_inner,
-                                              double tol_pr, double tol_du, AdmmCtl* ctl, bool writer) {
-  const int active = ctl->active;
-  if (it == 0) return active != 0;
-  const int lane = threadIdx.x & 63;
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  for (int b = lane; b < nparts; b += 64) {
-    const double* pb = part_prev + (int64_t)b * 4;
-    s0 += pb[0]; s1 += pb[1]; s2 += pb[2]; s3 += pb[3];
-  }
-  for (int off = 32; off > 0; off >>= 1) {       // butterfly: every lane ends with the same total
-    s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off);
-    s2 += __shfl_xor(s2, off); s3 += __shfl_xor(s3, off);
-  }
-  const double pr = sqrt(s0) / sqrt(s1);                                   // :1085
-  const double sc = sqrt(s2);
-  const double du = sc > 0 ? sqrt(s3) / sc : sqrt(s3);                     // :1087-1092
-  const bool cont = it < max_inner && (pr > tol_pr || du > tol_du);        // :600
-  if (writer && active) {
-    ctl->res[1] = pr;
-    ctl->res[3] = du;
-    ctl->iters = it;
-    if (!cont) ctl->active = 0;
-  }
-  return active != 0 && cont;
-}
 
 struct FusedArgs {
   const double *A, *L, *rho, *Binv;
@@ -393,12 +366,9 @@ int admm_partials(int64_t rows) {
 }
 
 // records the residuals / iteration count of the last executed inner iteration when the loop ran to
-// MaxInnerIters (an earlier exit was recorded by the iteration that detected it)
-__global__ void admm_loop_end_k(const double* part, int nparts, int max_inner, double tol_pr, double tol_du,
-                                AdmmCtl* ctl) {
-  (void)admm_continue(part + (int64_t)((max_inner + 1) & 1) * kMaxParts * 4, nparts, max_inner, max_inner, tol_pr,
-                      tol_du, ctl, threadIdx.x == 0);
-}
+// MaxInnerIters (an earlier exit was recorded by the iteration that detected it).  The solver folds this
+// into the Gram kernel that follows every mode update (atb_small); the kernel is for callers without one.
+__global__ void admm_loop_end_k(LoopEnd le) { loop_end_eval(le); }
 
 // element-wise dual update after a column-wise prox: mu += fac - Znew ; Z <- Znew ; partial norms
 __global__ void dual_update_k(const double* fac, double* Z, double* mu, const double* Znew, int64_t n,
@@ -762,6 +732,231 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_par_k(ColArgs a, const dou
   }
 }
 
+// Second form of the same split/merge iteration, built on prefix sums so that no step is sequential in a
+// segment's length: with Pc[i] = sum_{t<i} (y_t - c) (c = mean(y), which keeps the prefix sums small) the value
+// of segment [sa, sb] is  c + (Pc[sb+1] - Pc[sa] + lam*(J[sb] - J[sa-1])) / len  and the dual at an interior
+// point is  u_i = -lam*J[sa-1] + (Pc[i+1] - Pc[sa]) - (v - c)*(i - sa + 1),  both O(1).  A round is: scan the
+// segment starts, one thread per segment for the values, one per boundary for the merge test, every thread
+// walks its own 8-16 entries for the split test and the per-segment worst violation is found with a 64-bit
+// LDS max (magnitude bits above, index in the low 12 bits).  ~8 barriers per round, 1-3 rounds warm-started.
+// With `fz` the kernel also does the dual update of the ADMM iteration for its column (mu = V - Z_new,
+// Z <- Z_new) and the four residual sums, which removes the separate dual kernel.
+struct TvFused {
+  double* Z = nullptr;      // in: previous Z (warm start), out: new Z
+  double* mu = nullptr;     // in/out
+  double* part = nullptr;   // [R][4]: ||fac-Z||^2, ||fac||^2, ||mu||^2, ||Z-Zold||^2 of this column
+  int64_t ld = 0;
+};
+__global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const double* warm, int64_t ldw, TvFused fz,
+                                                             const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  extern __shared__ double dyn[];
+  __shared__ int wsum[4];
+  __shared__ double dsum[4];
+  __shared__ int flag_merge, flag_split;
+  const int n = (int)a.rows;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int r = blockIdx.x;
+  const double* vin = a.V + a.ldv * r;
+  double* z = a.Z + a.ldz * r;
+  const double lam = a.p0 / (a.rho[0] * a.rho_mul);
+  double* y = dyn;                                                 // n
+  double* Pc = dyn + n;                                            // n + 1
+  double* val = dyn + 2 * n + 1;                                   // n
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(dyn + 3 * n + 1);   // n
+  int* start = reinterpret_cast<int*>(dyn + 4 * n + 1);            // n + 1
+  signed char* J = reinterpret_cast<signed char*>(start + n + 1);  // n
+  const int chunk = (n + kTvThreads - 1) / kTvThreads;
+  const int c0 = min(n, t * chunk), c1 = min(n, c0 + chunk);
+  // ---- load (coalesced, all loads of a thread independent: a chunk-ordered loop would serialise 8-16 memory
+  // round trips), mean, centred prefix sums.  The warm-start column is staged in `val` the same way.
+  {
+    const double* wv = warm ? warm + ldw * r : nullptr;
+#pragma unroll 4
+    for (int i = t; i < n; i += kTvThreads) {
+      y[i] = vin[i];
+      if (wv) val[i] = wv[i];
+    }
+  }
+  __syncthreads();
+  double loc = 0.0;
+  for (int i = c0; i < c1; ++i) loc += y[i];
+  auto block_scan_d = [&](double v, double& total) {               // exclusive scan over threads, fixed order
+    double inc = v;
+    for (int off = 1; off < 64; off <<= 1) { const double u = __shfl_up(inc, off); if (lane >= off) inc += u; }
+    if (lane == 63) dsum[w] = inc;
+    __syncthreads();
+    double base = 0.0;
+    for (int q = 0; q < w; ++q) base += dsum[q];
+    total = dsum[0] + dsum[1] + dsum[2] + dsum[3];
+    __syncthreads();
+    return base + inc - v;
+  };
+  double tot;
+  (void)block_scan_d(loc, tot);
+  const double c = n > 0 ? tot / n : 0.0;
+  if (!(lam > 0.0)) {
+    for (int i = c0; i < c1; ++i) val[i] = y[i];
+  } else {
+    double locc = 0.0;
+    for (int i = c0; i < c1; ++i) locc += y[i] - c;
+    double tot2;
+    double run = block_scan_d(locc, tot2);
+    for (int i = c0; i < c1; ++i) { Pc[i] = run; run += y[i] - c; }
+    (void)tot2;
+    if (c1 == n && c0 < n) Pc[n] = run;                            // the thread holding the last entry
+    // ---- warm start of the jump set
+    if (warm) {
+      for (int i = c0; i < c1; ++i) {
+        if (i < n - 1) { const double d = val[i + 1] - val[i]; J[i] = d > 0 ? 1 : (d < 0 ? -1 : 0); }
+        else J[i] = 0;
+      }
+    } else {
+      for (int i = c0; i < c1; ++i) J[i] = 0;
+    }
+    __syncthreads();
+    const double thr = lam * (1.0 + 1e-11) + 1e-13 * (fabs(c) + 1.0);
+    const int max_rounds = 4 * n + 64;
+    bool converged = false;
+    for (int round = 0; round < max_rounds; ++round) {
+      // 1. segment starts: i == 0 or a jump between i-1 and i
+      int cnt = 0;
+      for (int i = c0; i < c1; ++i) cnt += (i == 0 || J[i - 1] != 0) ? 1 : 0;
+      int inc = cnt;
+      for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(inc, off); if (lane >= off) inc += u; }
+      if (lane == 63) wsum[w] = inc;
+      if (t == 0) { flag_merge = 0; flag_split = 0; }
+      __syncthreads();
+      int base = 0;
+      for (int q = 0; q < w; ++q) base += wsum[q];
+      const int first_seg = base + inc - cnt;                      // starts before this thread's chunk
+      {
+        int pos = first_seg;
+        for (int i = c0; i < c1; ++i)
+          if (i == 0 || J[i - 1] != 0) start[pos++] = i;
+      }
+      const int nseg = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      if (t == 0) start[nseg] = n;
+      __syncthreads();
+      // 2. segment values
+      for (int sgi = t; sgi < nseg; sgi += kTvThreads) {
+        const int sa = start[sgi], sb = start[sgi + 1] - 1;
+        const double sl = sa == 0 ? 0.0 : (double)J[sa - 1];
+        const double sr = sb == n - 1 ? 0.0 : (double)J[sb];
+        val[sgi] = c + (Pc[sb + 1] - Pc[sa] + lam * (sr - sl)) / (double)(sb - sa + 1);
+        best[sgi] = 0ull;
+      }
+      __syncthreads();
+      // 3. merge jumps whose sign disagrees with the values on both sides
+      for (int sgi = t; sgi + 1 < nseg; sgi += kTvThreads) {
+        const int jp = start[sgi + 1] - 1;
+        if ((double)J[jp] * (val[sgi + 1] - val[sgi]) <= 0.0) { J[jp] = 0; flag_merge = 1; }
+      }
+      __syncthreads();
+      const int merged = flag_merge;
+      __syncthreads();                                             // everyone has read the flag before it is reset
+      if (merged) continue;
+      // 4. split segments whose interior dual leaves [-lam, lam]: per-segment worst violation
+      {
+        int sgi = first_seg - ((c0 < c1 && (c0 == 0 || J[c0 - 1] != 0)) ? 0 : 1);   // segment of entry c0
+        for (int i = c0; i < c1; ++i) {
+          if (i != c0 && J[i - 1] != 0) ++sgi;
+          const int sa = start[sgi], sb = start[sgi + 1] - 1;
+          if (i >= sb) continue;                                   // the segment's last entry carries the jump itself
+          const double u0 = sa == 0 ? 0.0 : -lam * (double)J[sa - 1];
+          const double u = u0 + (Pc[i + 1] - Pc[sa]) - (val[sgi] - c) * (double)(i - sa + 1);
+          const double au = fabs(u);
+          if (au > thr) {
+            const unsigned long long key = ((unsigned long long)__double_as_longlong(au) & ~0xfffull) | (unsigned long long)i;
+            atomicMax(&best[sgi], key);
+          }
+        }
+      }
+      __syncthreads();
+      for (int sgi = t; sgi < nseg; sgi += kTvThreads) {
+        const unsigned long long b = best[sgi];
+        if (b != 0ull) {
+          const int i = (int)(b & 0xfffull);
+          const int sa = start[sgi];
+          const double u0 = sa == 0 ? 0.0 : -lam * (double)J[sa - 1];
+          const double u = u0 + (Pc[i + 1] - Pc[sa]) - (val[sgi] - c) * (double)(i - sa + 1);
+          J[i] = u > 0 ? -1 : 1;
+          flag_split = 1;
+        }
+      }
+      __syncthreads();
+      const int split = flag_split;
+      __syncthreads();
+      if (!split) { converged = true; break; }
+    }
+    if (converged) {
+      // expand: entry i takes the value of its segment (val is indexed by segment; write through `best` as doubles
+      // would alias, so expand into y, which is no longer needed)
+      int sgi = 0;
+      {
+        int cnt = 0;
+        for (int i = c0; i < c1; ++i) cnt += (i == 0 || J[i - 1] != 0) ? 1 : 0;
+        int inc = cnt;
+        for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(inc, off); if (lane >= off) inc += u; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int base = 0;
+        for (int q = 0; q < w; ++q) base += wsum[q];
+        sgi = base + inc - cnt - ((c0 < c1 && (c0 == 0 || J[c0 - 1] != 0)) ? 0 : 1);
+      }
+      for (int i = c0; i < c1; ++i) {
+        if (i != c0 && J[i - 1] != 0) ++sgi;
+        Pc[i] = val[sgi];                                          // Pc is free now: holds the solution
+      }
+      __syncthreads();
+      for (int i = c0; i < c1; ++i) val[i] = Pc[i];
+    } else {
+      __syncthreads();
+      if (t == 0) tv1d_condat_dev(y, val, n, lam);                 // exact sequential fallback
+    }
+  }
+  __syncthreads();
+  // ---- write the column; optionally the ADMM dual update and residual sums for it
+  if (fz.Z == nullptr) {
+    for (int i = t; i < n; i += kTvThreads) z[i] = val[i];
+    return;
+  }
+  double* Zc = fz.Z + fz.ld * r;
+  double* muc = fz.mu + fz.ld * r;
+  double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+  constexpr int kPer = kTvParMax / kTvThreads;                     // entries per thread at the largest n
+  double mo[kPer], zo[kPer];
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {                                 // all loads first: stores below may alias them
+    const int i = t + k * kTvThreads;
+    mo[k] = i < n ? muc[i] : 0.0;
+    zo[k] = i < n ? Zc[i] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int i = t + k * kTvThreads;
+    if (i < n) {
+      const double zn = val[i], vv = y[i];
+      const double x = vv - mo[k];                                 // fac = V - mu_old
+      const double mn = vv - zn;                                   // mu + fac - Z   (:1428)
+      Zc[i] = zn;
+      muc[i] = mn;
+      const double d = x - zn, e = zn - zo[k];
+      s1 += d * d; s2 += x * x; s3 += mn * mn; s4 += e * e;
+    }
+  }
+  double q4[4] = {s1, s2, s3, s4};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    double v = q4[q];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) dsum[w] = v;
+    __syncthreads();
+    if (t == 0) fz.part[(int64_t)r * 4 + q] = (dsum[0] + dsum[1]) + (dsum[2] + dsum[3]);
+    __syncthreads();
+  }
+}
+
 // isotonic regression (PAVA), non-decreasing; `sign` = -1 gives -project_monotone(-x) (:26,:28)
 __global__ void prox_monotone_k(ColArgs a, double sign, const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
@@ -1059,6 +1254,19 @@ size_t prox_ws_bytes(int type, int64_t rows, int R) {
   }
 }
 
+static size_t tv_fast_lds(int64_t rows) { return (size_t)(4 * rows + 2) * 8 + (size_t)(rows + 2) * 4 + (size_t)rows + 64; }
+static void tv_fast_launch(const ColArgs& a, const double* warm, int64_t ldw, const TvFused& fz, const AdmmCtl* ctl,
+                           hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prox_tv_fast_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)tv_fast_lds(kTvParMax)));
+    attr = true;
+  }
+  prox_tv_fast_k<<<a.R, kTvThreads, tv_fast_lds(a.rows), s>>>(a, warm, ldw, fz, ctl);
+  AO_KERNEL_CHECK();
+}
+
 void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, int64_t ldz,
                 int64_t rows, int R, const double* rho_dev, double rho_mul, double* ws,
                 const AdmmCtl* ctl, hipStream_t s, const double* warm, int64_t ldw) {
@@ -1084,14 +1292,7 @@ void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, 
       break;
     case AOADMM_C_TV: {
       if (rows <= kTvParMax) {
-        const size_t sh = (size_t)21 * rows + 64;
-        static bool attr_par = false;
-        if (!attr_par) {
-          AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prox_tv_par_k),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(21 * kTvParMax + 64)));
-          attr_par = true;
-        }
-        prox_tv_par_k<<<R, kTvThreads, sh, s>>>(a, warm, ldw, ctl);
+        tv_fast_launch(a, warm, ldw, TvFused(), ctl, s);
         break;
       }
       const int use_lds = rows <= kTvLdsRows;
@@ -1158,7 +1359,8 @@ static void launch_row_iteration(const FusedArgs& a, unsigned blocks, hipStream_
 }
 
 void admm_constrained_loop(const AdmmMode& m, double* part, double* V, double* Znew, double* prox_ws,
-                           AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du, hipStream_t s) {
+                           AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du, hipStream_t s,
+                           LoopEnd* deferred_end) {
   FusedArgs a;
   a.A = m.A; a.L = m.L; a.Binv = m.Binv; a.rho = m.rho; a.fac = m.fac; a.Z = m.Z; a.mu = m.mu; a.V = V; a.part = part;
   a.ctl = ctl;
@@ -1171,20 +1373,34 @@ void admm_constrained_loop(const AdmmMode& m, double* part, double* V, double* Z
   const int64_t n = m.rows * m.R;
   int64_t nbd = cdiv(n, 1024);
   if (nbd > 64) nbd = 64;
-  const int nparts = a.fused ? (int)blocks : (int)nbd;
+  const bool tv_fused = !a.fused && m.prox.type == AOADMM_C_TV && m.rows <= kTvParMax;   // prox + dual in one kernel
+  const int nparts = a.fused ? (int)blocks : (tv_fused ? m.R : (int)nbd);
   for (int it = 0; it < max_inner; ++it) {
     a.it = it;
     a.nparts_prev = nparts;
     launch_row_iteration(a, blocks, s);
     AO_KERNEL_CHECK();
-    if (!a.fused) {
+    if (tv_fused) {
+      ColArgs ca;
+      ca.V = V; ca.Z = Znew; ca.ldv = m.rows; ca.ldz = m.rows; ca.rows = m.rows; ca.R = m.R; ca.type = m.prox.type;
+      ca.p0 = m.prox.p0; ca.p1 = m.prox.p1; ca.rho = m.rho; ca.rho_mul = 1.0; ca.ws = prox_ws;
+      TvFused fz;
+      fz.Z = m.Z; fz.mu = m.mu; fz.part = part + (int64_t)(it & 1) * kMaxParts * 4; fz.ld = m.rows;
+      tv_fast_launch(ca, m.Z, m.rows, fz, ctl, s);
+    } else if (!a.fused) {
       prox_apply(m.prox, V, m.rows, Znew, m.rows, m.rows, m.R, m.rho, 1.0, prox_ws, ctl, s, m.Z, m.rows);
       dual_update_k<<<(unsigned)nbd, 256, 0, s>>>(m.fac, m.Z, m.mu, Znew, n, part + (int64_t)(it & 1) * kMaxParts * 4, ctl);
       AO_KERNEL_CHECK();
     }
   }
-  admm_loop_end_k<<<1, 64, 0, s>>>(part, nparts, max_inner, tol_pr, tol_du, ctl);
-  AO_KERNEL_CHECK();
+  LoopEnd le;
+  le.part = part; le.nparts = nparts; le.max_inner = max_inner; le.tol_pr = tol_pr; le.tol_du = tol_du; le.ctl = ctl;
+  if (deferred_end) {
+    *deferred_end = le;
+  } else {
+    admm_loop_end_k<<<1, 64, 0, s>>>(le);
+    AO_KERNEL_CHECK();
+  }
 }
 
 __global__ void copy_add_k(double* V, double* Zold, const double* fac, const double* Z, const double* mu, int64_t n,

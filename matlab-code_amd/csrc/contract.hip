@@ -1086,8 +1086,9 @@ static void launch_inner_t(const void* T, int nchunk, int64_t trows, int64_t A, 
 
 void launch_reduce_inner(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
                          int64_t B, int R, const double* Fa, int64_t ldFa, double scale,
-                         double* out, int64_t ldOut, double* ft_scratch, hipStream_t s) {
-  factor_rowmajor(Fa, ldFa, A, R, ft_scratch, s);
+                         double* out, int64_t ldOut, double* ft_scratch, hipStream_t s, const double* FaT) {
+  if (FaT) ft_scratch = const_cast<double*>(FaT);    // row-major copy already maintained by the caller
+  else factor_rowmajor(Fa, ldFa, A, R, ft_scratch, s);
   // 16-byte loads need every slab (Apad*R elements) and every chunk (trows*R) to start 16-byte aligned
   if (tprec == AOADMM_PREC_F32) {
     if (R % 4 == 0) launch_inner_t<float, 4>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s);
@@ -1190,8 +1191,10 @@ static void launch_outer_t(const void* T, int nchunk, int64_t trows, int64_t A, 
 
 void launch_reduce_outer(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
                          int64_t B, int R, const double* Fb, int64_t ldFb, double scale,
-                         double* out, int64_t ldOut, double* scratch, double* ft_scratch, hipStream_t s) {
-  factor_rowmajor(Fb, ldFb, B, R, ft_scratch, s);
+                         double* out, int64_t ldOut, double* scratch, double* ft_scratch, hipStream_t s,
+                         const double* FbT) {
+  if (FbT) ft_scratch = const_cast<double*>(FbT);
+  else factor_rowmajor(Fb, ldFb, B, R, ft_scratch, s);
   int SB = 1;
   const int vec = outer_vec(tprec, R);
   if (tprec == AOADMM_PREC_F32) {

@@ -37,8 +37,12 @@ void gemm_small(double* out, int64_t ldo, const double* A, int64_t lda, const do
                 hipStream_t s);
 // out = A' * B  (A: I x K, B: I x N, K,N <= 64) deterministic two-stage reduction; ws >= gram_ws_bytes
 size_t atb_ws_bytes(int64_t I, int K, int N);
+struct LoopEnd;
+// `At_rowmajor` (optional, I x K doubles): row-major copy of A written on the way (the T reductions read the factor
+// in that order); `close` (optional): closing record of the ADMM loop that produced A, evaluated by block 0.
 void atb_small(double* out, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t I,
-               int K, int N, double* ws, const AdmmCtl* ctl, hipStream_t s);
+               int K, int N, double* ws, const AdmmCtl* ctl, hipStream_t s, double* At_rowmajor = nullptr,
+               const LoopEnd* close = nullptr);
 // slot[0] = sum (x-y)^2 (y may be null) ; ws >= 64 doubles
 void sumsq_diff(double* slot, const double* x, const double* y, int64_t n, double* ws,
                 const AdmmCtl* ctl, hipStream_t s);

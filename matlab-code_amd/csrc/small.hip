@@ -1,6 +1,7 @@
 // Small dense fp64 primitives (see small.h).  Reference lines are cited at each kernel.
 #include "small.h"
 #include "device_utils.h"
+#include "loopctl.h"
 
 #include <algorithm>
 
@@ -91,8 +92,9 @@ size_t atb_ws_bytes(int64_t I, int K, int N) { return (size_t)atb_blocks(I) * K 
 // block b owns rows [b*rpb, (b+1)*rpb): tiles of 64 rows of A and B are staged in LDS (coalesced
 // column reads), every thread accumulates its (k,n) outputs over the tile in a fixed order
 __global__ void atb_part_k(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t I, int K, int N,
-                           double* ws, const AdmmCtl* ctl) {
+                           double* ws, const AdmmCtl* ctl, double* At, LoopEnd le) {
   CTL_GUARD(ctl);
+  if (le.ctl != nullptr && blockIdx.x == 0 && threadIdx.x < 64) loop_end_eval(le);   // first wave of block 0
   extern __shared__ double tile[];           // [kAtbRows][K] then [kAtbRows][N], row-major, padded by 1
   const int Kp = K + 1, Np = N + 1;
   double* ta = tile;
@@ -118,6 +120,11 @@ __global__ void atb_part_k(const double* A, int64_t lda, const double* B, int64_
       tb[i * Np + n] = B[r0 + i + ldb * n];
     }
     __syncthreads();
+    if (At)                                        // row-major copy of the staged rows (contiguous store)
+      for (int e = threadIdx.x; e < nr * K; e += blockDim.x) {
+        const int i = e / K, k = e - i * K;
+        At[(r0 + i) * K + k] = ta[i * Kp + k];
+      }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int e = threadIdx.x + q * 256;
@@ -155,10 +162,10 @@ __global__ __launch_bounds__(256) void atb_fin_k(double* out, const double* ws, 
   }
 }
 void atb_small(double* out, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t I,
-               int K, int N, double* ws, const AdmmCtl* ctl, hipStream_t s) {
+               int K, int N, double* ws, const AdmmCtl* ctl, hipStream_t s, double* At_rowmajor, const LoopEnd* close) {
   const int nb = atb_blocks(I);
   const size_t sh = (size_t)kAtbRows * (K + N + 2) * sizeof(double);
-  atb_part_k<<<nb, 256, sh, s>>>(A, lda, B, ldb, I, K, N, ws, ctl);
+  atb_part_k<<<nb, 256, sh, s>>>(A, lda, B, ldb, I, K, N, ws, ctl, At_rowmajor, close ? *close : LoopEnd());
   AO_KERNEL_CHECK();
   atb_fin_k<<<(unsigned)cdiv(K * N, 32), 256, 0, s>>>(out, ws, nb, K * N, ctl);
   AO_KERNEL_CHECK();
@@ -388,9 +395,9 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-template <int RMAX>
+template <int RMAX, bool EXACT>          // EXACT: R == RMAX, every rank test folds away (a third of the instructions)
 __global__ __launch_bounds__(64) void sys_build_k(SysBuild sb) {
-  const int R = sb.R, t = threadIdx.x;
+  const int R = EXACT ? RMAX : sb.R, t = threadIdx.x;
   const bool mine = t < R;
   double row[RMAX];                              // row t of C, then of B + nrho*rho/2*I, then of L
   // all loads of one Gram matrix are issued together on clamped (always valid) addresses: one memory
@@ -489,11 +496,15 @@ __global__ __launch_bounds__(64) void sys_build_k(SysBuild sb) {
 void sys_build(const SysBuild& sb, hipStream_t s) {
   AO_REQUIRE(sb.R >= 1 && sb.R <= kMaxRank, "sys_build: bad R");
   static_assert(kMaxRank <= 64, "sys_build_k maps one lane to one row");
-  if (sb.R <= 8) sys_build_k<8><<<1, 64, 0, s>>>(sb);
-  else if (sb.R <= 16) sys_build_k<16><<<1, 64, 0, s>>>(sb);
-  else if (sb.R <= 20) sys_build_k<20><<<1, 64, 0, s>>>(sb);
-  else if (sb.R <= 32) sys_build_k<32><<<1, 64, 0, s>>>(sb);
-  else sys_build_k<64><<<1, 64, 0, s>>>(sb);
+#define AO_SB(RM) { if (sb.R == RM) sys_build_k<RM, true><<<1, 64, 0, s>>>(sb); else sys_build_k<RM, false><<<1, 64, 0, s>>>(sb); }
+  if (sb.R <= 4) AO_SB(4)
+  else if (sb.R <= 8) AO_SB(8)
+  else if (sb.R <= 12) AO_SB(12)
+  else if (sb.R <= 16) AO_SB(16)
+  else if (sb.R <= 20) AO_SB(20)
+  else if (sb.R <= 32) AO_SB(32)
+  else AO_SB(64)
+#undef AO_SB
   AO_KERNEL_CHECK();
 }
 

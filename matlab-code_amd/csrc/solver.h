@@ -21,6 +21,7 @@ struct FactorRef {
   const double* p;    // device, column-major
   int64_t ld;
   uint64_t version;
+  const double* pT = nullptr;   // optional row-major copy (rows x R) of the same version, written by the Gram kernel
 };
 
 // One dense CP block (tensor or matrix) and its partial-contraction cache.
@@ -63,6 +64,8 @@ struct ModeInfo {
   int64_t hr = 0, hc = 0, h2r = 0, h2c = 0;
   double ridge = 0.0;
   DevBuf fac, Z, mu, muD;
+  DevBuf facT;             // row-major copy of fac (by-product of the Gram kernel), valid while facT_version == version
+  uint64_t facT_version = 0;
   bool has_fac = false, has_Z = false, has_mu = false, has_muD = false;
   int64_t muD_rows = 0, muD_cols = 0;
   uint64_t version = 1;
@@ -177,7 +180,10 @@ class Engine {
 
  private:
   void check_mode(int m) const;
-  void compute_gram(ModeInfo& mi);
+  void compute_gram(ModeInfo& mi, const LoopEnd* close = nullptr);
+  FactorRef factor_ref(const ModeInfo& o) const {
+    return FactorRef{o.fac.d(), o.rows, o.version, o.facT_version == o.version ? o.facT.d() : nullptr};
+  }
   void update_uncoupled_cp_mode(int m, const aoadmm_options& opt);
   void prepare_mode_system(int m, int nrho, const aoadmm_options& opt);
   void coupled_admm(int c, const aoadmm_options& opt);

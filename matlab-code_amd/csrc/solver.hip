@@ -789,7 +789,7 @@ void Engine::prefetch_next_contraction(const aoadmm_options& opt) {
         FactorRef facs[8];
         for (int i = 0; i < t.nmodes; ++i) {
           const ModeInfo& o = modes_[t.modes[i]];
-          facs[i] = FactorRef{o.fac.d(), o.rows, o.version};
+          facs[i] = factor_ref(o);
         }
         std::vector<int> seq = update_sequence(p);
         ensure_contraction(t.blk, mi.pos, facs, mi.R, true, seq.data(), (int)seq.size());
@@ -844,12 +844,13 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
       b.scratch.ensure(reduce_outer_scratch_bytes(An, Bn, R));
       b.ft.ensure(reduce_factor_scratch_bytes(Bn, R));
       launch_reduce_outer(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, facs[ib].p, facs[ib].ld, scale,
-                          out_local, ldOut, b.scratch.d(), b.ft.d(), stream_);
+                          out_local, ldOut, b.scratch.d(), b.ft.d(), stream_, facs[ib].pT);
     } else {
       AO_REQUIRE(pos == ib, "internal: cached contraction cannot serve this mode");
       b.ft.ensure(reduce_factor_scratch_bytes(An, R));
+      const double* FaT = facs[ia].pT ? facs[ia].pT + ((ia == 0 && sharded) ? b.row0 * R : 0) : nullptr;
       launch_reduce_inner(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, Fa, facs[ia].ld, scale, out_local,
-                          ldOut, b.ft.d(), stream_);
+                          ldOut, b.ft.d(), stream_, FaT);
     }
   } else {
     // N-way (N > 3): contract the last mode (or the one before it when pos is last), then fold the
@@ -888,8 +889,13 @@ void Engine::ensure_mode_work(ModeInfo& mi) {
   atbws_.ensure(atb_ws_bytes(mi.rows, mi.R, mi.R));
 }
 
-void Engine::compute_gram(ModeInfo& mi) {
-  atb_small(mi.gram.d(), mi.fac.d(), mi.rows, mi.fac.d(), mi.rows, mi.rows, mi.R, mi.R, atbws_.d(), nullptr, stream_);
+// Gram of the current factor (:66, :148); the same kernel leaves a row-major copy of the factor for the T
+// reductions and closes the ADMM loop that produced the factor.  Call BEFORE bumping mi.version.
+void Engine::compute_gram(ModeInfo& mi, const LoopEnd* close) {
+  mi.facT.ensure((size_t)mi.rows * mi.R * sizeof(double));
+  atb_small(mi.gram.d(), mi.fac.d(), mi.rows, mi.fac.d(), mi.rows, mi.rows, mi.R, mi.R, atbws_.d(), nullptr, stream_,
+            mi.facT.d(), close);
+  mi.facT_version = mi.version;
 }
 
 void Engine::prepare_mode_system(int m, int nrho, const aoadmm_options& opt) {
@@ -903,7 +909,7 @@ void Engine::prepare_mode_system(int m, int nrho, const aoadmm_options& opt) {
   FactorRef facs[8];
   for (int i = 0; i < t.nmodes; ++i) {
     const ModeInfo& o = modes_[t.modes[i]];
-    facs[i] = FactorRef{o.fac.d(), o.rows, o.version};
+    facs[i] = factor_ref(o);
   }
   std::vector<int> seq = update_sequence(mi.tensor);
   block_mttkrp(t.blk, mi.pos, facs, mi.R, t.weight, mi.A.d(), mi.rows, opt.use_dimtree != 0, seq.data(), (int)seq.size());
@@ -942,6 +948,7 @@ void Engine::update_uncoupled_cp_mode(int m, const aoadmm_options& opt) {
   ModeInfo& mi = modes_[m];
   prepare_mode_system(m, mi.constrained ? 1 : 0, opt);
   AdmmCtl* ctl = ctl_of_mode(m);
+  LoopEnd le;
   if (!mi.constrained) {
     // G.fac{m} = A{m}/B{m}  (:134): B is symmetric positive definite -> Cholesky solve
     row_solve(mi.fac.d(), mi.rows, mi.Aeff, mi.rows, mi.L.d(), mi.rows, mi.R, nullptr, stream_);
@@ -951,10 +958,10 @@ void Engine::update_uncoupled_cp_mode(int m, const aoadmm_options& opt) {
     am.fac = mi.fac.d(); am.Z = mi.Z.d(); am.mu = mi.mu.d();
     am.rows = mi.rows; am.R = mi.R; am.prox = mi.prox;
     admm_constrained_loop(am, mi.part.d(), mi.V.d(), mi.Znew.d(), mi.proxws.d(), ctl, opt.MaxInnerIters,
-                          opt.innerRelPrTol_constr, opt.innerRelDualTol_constr, stream_);
+                          opt.innerRelPrTol_constr, opt.innerRelDualTol_constr, stream_, &le);
   }
-  compute_gram(mi);                                                           // :148
   mi.version++;
+  compute_gram(mi, le.ctl ? &le : nullptr);                                   // :148
 }
 
 // The six linear couplings (cmtf_fun_AOADMM.m:625-1075) in one form:  Tf_m(C_m) = Sd_m(Delta)
@@ -1224,7 +1231,7 @@ void Engine::eval_objective_enqueue(bool first) {
       FactorRef facs[8];
       for (int i = 0; i < t.nmodes; ++i) {
         const ModeInfo& o = modes_[t.modes[i]];
-        facs[i] = FactorRef{o.fac.d(), o.rows, o.version};
+        facs[i] = factor_ref(o);
       }
       std::vector<int> seq = update_sequence(p);
       block_mttkrp(t.blk, 0, facs, m0.R, t.weight, m0.A.d(), m0.rows, true, seq.data(), (int)seq.size());
@@ -1474,7 +1481,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
           }
       if (cid >= 0) {
         coupled_admm(cid, opt);                                                // :277 / :366
-        for (int m : cm) { compute_gram(modes_[m]); modes_[m].version++; }      // :393-403
+        for (int m : cm) { modes_[m].version++; compute_gram(modes_[m]); }      // :393-403
       }
     }
     if (has_miss)                                                              // EM imputation (:408-441)
@@ -1531,7 +1538,7 @@ void Engine::resident_mttkrp(int p, int pos, double* out_host, float* ms) {
   for (int i = 0; i < t.nmodes; ++i) {
     ModeInfo& o = modes_[t.modes[i]];
     AO_REQUIRE(o.has_fac, "G.fac{%d} missing", t.modes[i] + 1);
-    facs[i] = FactorRef{o.fac.d(), o.rows, o.version};
+    facs[i] = factor_ref(o);
   }
   ModeInfo& mi = modes_[t.modes[pos]];
   ensure_mode_work(mi);
