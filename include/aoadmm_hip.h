@@ -206,6 +206,12 @@ int aoadmm_kernel_stats(aoadmm_ctx* ctx, int which, int reset, double* contract_
 /* mttkrp(X,U,n): cmtf_fun_AOADMM.m:97, cp_func.m:47.  X dense, dims[ndims]; U[m] is dims[m] x R */
 int aoadmm_op_mttkrp(aoadmm_ctx* ctx, const double* X, int ndims, const int64_t* dims,
                      const double* const* U, int R, int n, int precision, double* out);
+/* Y = X_(n)*X_(n)' (dims[n] x dims[n]) of a dense matrix / 3-way tensor: the Gram matrix whose leading eigenvectors
+ * initialise mode n when init_options.nvecs = 1 (cmtf_nvecs.m:40-58, init_coupled_AOADMM_CMTF.m:50-73; for a
+ * PARAFAC2 block pass [X_1 ... X_K] with n = 0, or X_k with n = 1).  The eigenvectors are taken by the caller
+ * (MATLAB `eigs`, numpy `eigh`). */
+int aoadmm_op_unfold_gram(aoadmm_ctx* ctx, const double* X, int ndims, const int64_t* dims, int n, int precision,
+                          double* out);
 /* G'*G : cmtf_fun_AOADMM.m:66,148 */
 int aoadmm_op_gram(aoadmm_ctx* ctx, const double* F, int64_t rows, int R, double* out);
 /* L = chol(B','lower') : cmtf_fun_AOADMM.m:142 ; AOADMM_ERR_NOT_PD on failure */

@@ -13,9 +13,9 @@ without a GPU (so the C ABI can be inspected), creating an `Engine` does not.
 from ._capi import (AoadmmError, NotPositiveDefinite, UnsupportedOnDevice, LIB_PATH, SYMBOLS, load_library)
 from .engine import CONSTRAINT_IDS, Engine, constraint_descriptor, default_engine
 from .dist import init_engine_comm, row_block
-from .driver import (build_model, cmtf_AOADMM, constraints_to_prox, download_state, init_coupled_AOADMM_CMTF,
+from .driver import (build_model, cmtf_AOADMM, cmtf_nvecs, constraints_to_prox, download_state, init_coupled_AOADMM_CMTF,
                      run_solver, upload_state)
 
 __all__ = ['AoadmmError', 'NotPositiveDefinite', 'UnsupportedOnDevice', 'LIB_PATH', 'SYMBOLS', 'load_library',
            'CONSTRAINT_IDS', 'Engine', 'constraint_descriptor', 'default_engine', 'build_model', 'cmtf_AOADMM',
-           'constraints_to_prox', 'download_state', 'init_coupled_AOADMM_CMTF', 'run_solver', 'upload_state', 'init_engine_comm', 'row_block']
+           'cmtf_nvecs', 'constraints_to_prox', 'download_state', 'init_coupled_AOADMM_CMTF', 'run_solver', 'upload_state', 'init_engine_comm', 'row_block']

@@ -6,6 +6,7 @@
 #include <new>
 
 #include "solver.h"
+#include "misc.h"
 
 using namespace aoadmm;
 
@@ -258,6 +259,30 @@ int aoadmm_op_mttkrp(aoadmm_ctx* ctx, const double* X, int ndims, const int64_t*
     o.alloc((size_t)dims[n] * R * sizeof(double));
     e.block_mttkrp(blk, n, refs, R, 1.0, o.d(), dims[n], false, nullptr, 0);
     d2h(out, o, dims[n] * R, e.stream());
+  });
+}
+
+int aoadmm_op_unfold_gram(aoadmm_ctx* ctx, const double* X, int ndims, const int64_t* dims, int n, int precision,
+                          double* out) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(X && dims && out, "null pointer");
+    AO_REQUIRE((ndims == 2 || ndims == 3) && n >= 0 && n < ndims, "unfold_gram handles matrices and 3-way tensors");
+    Engine& e = *ctx->eng;
+    AO_HIP(hipSetDevice(e.device()));
+    CpBlock blk;
+    e.block_upload(blk, ndims, dims, X, precision, 0, dims[0]);
+    const int64_t I = dims[0], Ip = blk.X.pad0, J = dims[1], K = ndims == 3 ? dims[2] : 1;
+    UnfoldGramArgs a;
+    a.X = blk.X.data.p;
+    if (n == 0) { a.n = I; a.sa = 1; a.n1 = J * K; a.s1 = Ip; a.n2 = 1; a.s2 = 0; }
+    else if (n == 1) { a.n = J; a.sa = Ip; a.n1 = I; a.s1 = 1; a.n2 = K; a.s2 = Ip * J; }
+    else { a.n = K; a.sa = Ip * J; a.n1 = Ip * J; a.s1 = 1; a.n2 = 1; a.s2 = 0; }   // padding rows are zeros
+    DevBuf ws, y;
+    ws.alloc(unfold_gram_ws_bytes(a));
+    y.alloc((size_t)a.n * a.n * sizeof(double));
+    unfold_gram(a, precision, ws.d(), y.d(), e.stream());
+    d2h(out, y, a.n * a.n, e.stream());
   });
 }
 

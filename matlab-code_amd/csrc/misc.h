@@ -42,4 +42,13 @@ void reg_value(double* slot, int type, double p0, const double* X, int64_t rows,
 // uniform [0,1) fill (device RNG; used by tests/bench for factor initialisation on device)
 void fill_uniform(double* x, int64_t n, uint64_t seed, hipStream_t s);
 
+// Y = X_(n) X_(n)' of a resident dense block (cmtf_nvecs.m:56): row a of the unfolding at X + a*sa, reduction
+// over t1 < n1 (stride s1) x t2 < n2 (stride s2); Y is n x n column-major fp64.
+struct UnfoldGramArgs {
+  const void* X;
+  int64_t n, sa, n1, s1, n2, s2;
+};
+size_t unfold_gram_ws_bytes(const UnfoldGramArgs& a);
+void unfold_gram(const UnfoldGramArgs& a, int prec, double* ws, double* out, hipStream_t s);
+
 }  // namespace aoadmm

@@ -245,4 +245,93 @@ void reg_value(double* slot, int type, double p0, const double* X, int64_t rows,
   AO_KERNEL_CHECK();
 }
 
+// ---------------------------------------------------------------------------
+// Gram of a mode-n unfolding, Y = X_(n) X_(n)'  (functions/cmtf_nvecs.m:56: `Y = A*A'` for the SVD-based
+// initialisation; the leading eigenvectors are taken on the host).  Unfolding row a sits at X + a*sa; the
+// reduction runs over t1 < n1 (stride s1) and t2 < n2 (stride s2).  64 x 64 output tiles, 16 reduction
+// entries staged through LDS per step, fp64 accumulation; the reduction is split over gridDim.z and the
+// partial tiles are added in a fixed order by unfold_gram_sum_k.
+template <typename T>
+__global__ __launch_bounds__(256) void unfold_gram_k(UnfoldGramArgs a, double* ws) {
+  __shared__ double As[16][65], Bs[16][65];
+  const T* X = reinterpret_cast<const T*>(a.X);
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t a0 = (int64_t)blockIdx.x * 64, b0 = (int64_t)blockIdx.y * 64;
+  const int64_t nch1 = (a.n1 + 15) / 16, nchunks = nch1 * a.n2;
+  const int64_t per = (nchunks + gridDim.z - 1) / gridDim.z;
+  const int64_t c_lo = (int64_t)blockIdx.z * per;
+  int64_t c_hi = c_lo + per;
+  if (c_hi > nchunks) c_hi = nchunks;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  const bool row_contig = a.sa == 1;                  // which index is contiguous decides the load mapping
+  for (int64_t c = c_lo; c < c_hi; ++c) {
+    const int64_t t2 = c / nch1, t1_0 = (c - t2 * nch1) * 16;
+    const int64_t base = t2 * a.s2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int aa, tt;
+      if (row_contig) { aa = tid & 63; tt = (tid >> 6) + 4 * q; }
+      else { tt = tid & 15; aa = (tid >> 4) + 16 * q; }
+      const int64_t t1 = t1_0 + tt;
+      const bool tv = t1 < a.n1;
+      const int64_t off = base + (tv ? t1 : 0) * a.s1;
+      const int64_t ra = a0 + aa, rb = b0 + aa;
+      As[tt][aa] = (tv && ra < a.n) ? (double)X[ra * a.sa + off] : 0.0;
+      Bs[tt][aa] = (tv && rb < a.n) ? (double)X[rb * a.sa + off] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = As[tt][ty * 4 + i]; bv[i] = Bs[tt][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+    }
+    __syncthreads();
+  }
+  double* W = ws + (int64_t)blockIdx.z * a.n * a.n;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t ra = a0 + ty * 4 + i, rb = b0 + tx * 4 + j;
+      if (ra < a.n && rb < a.n) W[ra + a.n * rb] = acc[i][j];
+    }
+}
+__global__ void unfold_gram_sum_k(const double* ws, int64_t nn, int nz, double* out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nn) return;
+  double t = 0.0;
+  for (int z = 0; z < nz; ++z) t += ws[(int64_t)z * nn + e];
+  out[e] = t;
+}
+static int unfold_gram_splits(const UnfoldGramArgs& a) {
+  const int64_t tiles = cdiv(a.n, 64) * cdiv(a.n, 64);
+  const int64_t nchunks = cdiv(a.n1, 16) * a.n2;
+  int64_t z = cdiv(2048, tiles);
+  if (z > nchunks) z = nchunks;
+  if (z > 1024) z = 1024;
+  while (z > 1 && z * a.n * a.n * 8 > (int64_t)(1ll << 30)) z /= 2;   // partial tiles <= 1 GiB
+  return (int)(z < 1 ? 1 : z);
+}
+size_t unfold_gram_ws_bytes(const UnfoldGramArgs& a) { return (size_t)unfold_gram_splits(a) * a.n * a.n * sizeof(double); }
+void unfold_gram(const UnfoldGramArgs& a, int prec, double* ws, double* out, hipStream_t s) {
+  AO_REQUIRE(a.n > 0 && a.n1 > 0 && a.n2 > 0, "unfold_gram: bad sizes");
+  AO_REQUIRE(cdiv(a.n, 64) <= 65535, "unfold_gram: mode too long");
+  const int nz = unfold_gram_splits(a);
+  const dim3 grid((unsigned)cdiv(a.n, 64), (unsigned)cdiv(a.n, 64), (unsigned)nz);
+  if (prec == AOADMM_PREC_F32) unfold_gram_k<float><<<grid, 256, 0, s>>>(a, ws);
+  else unfold_gram_k<double><<<grid, 256, 0, s>>>(a, ws);
+  AO_KERNEL_CHECK();
+  unfold_gram_sum_k<<<(unsigned)cdiv(a.n * a.n, 256), 256, 0, s>>>(ws, a.n * a.n, nz, out);
+  AO_KERNEL_CHECK();
+}
+
 }  // namespace aoadmm

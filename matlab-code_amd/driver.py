@@ -74,12 +74,33 @@ def constraints_to_prox(constrained_modes, constraints, sz, engine=None):
     return prox_ops, reg
 
 
+def _leading_eigvecs(Y, r):
+    """`[U,~] = eigs(Y, r, 'LM')`: eigenvectors of the r eigenvalues of largest magnitude, in that order
+    (the sign of each vector is arbitrary, in MATLAB too)."""
+    w, V = np.linalg.eigh((Y + Y.T) / 2)
+    idx = np.argsort(-np.abs(w), kind='stable')[:r]
+    return np.asfortranarray(V[:, idx])
+
+
+def cmtf_nvecs(Z, n, r, engine=None):
+    """functions/cmtf_nvecs.m:1-58 for a CP block: first r left singular vectors of the mode-n unfolding (0-based n)
+    of the data set that owns mode n.  The I_n x I_n Gram matrix of the unfolding comes from the device
+    (`aoadmm_op_unfold_gram`), the r leading eigenvectors from LAPACK on the host."""
+    eng = engine or default_engine()
+    which_p = _which_p(Z)
+    p = which_p[n]
+    md = [m - 1 for m in Z['modes'][p]]
+    Y = eng.unfold_gram(np.asarray(Z['object'][p], dtype=np.float64), md.index(n))
+    return _leading_eigvecs(Y, r)
+
+
 def init_coupled_AOADMM_CMTF(Z, init_options, Delta=None, rng=None, engine=None):
-    """functions/init_coupled_AOADMM_CMTF.m:1-174 (random path, `nvecs = 0`)."""
+    """functions/init_coupled_AOADMM_CMTF.m:1-174: random initialisation (`nvecs = 0`) or SVD-based (`nvecs = 1`,
+    :50-73), the latter with the unfolding Gram matrices computed on the device."""
     if rng is None:
         rng = np.random.default_rng()
-    if init_options.get('nvecs', 0):
-        raise capi.UnsupportedOnDevice(capi.ERR_UNSUPPORTED, 'nvecs initialisation (cmtf_nvecs.m) stays on the MATLAB path')
+    nvecs = bool(init_options.get('nvecs', 0))
+    eng_nv = (engine or default_engine()) if nvecs else None
     sz = Z['size']
     lambdas = init_options['lambdas_init']
     distr = init_options['distr']
@@ -101,6 +122,25 @@ def init_coupled_AOADMM_CMTF(Z, init_options, Delta=None, rng=None, engine=None)
         md = [m - 1 for m in Z['modes'][p]]
         R = len(lambdas[p])
         for n in md:
+            if nvecs:                                                           # :50-73
+                if Z['model'][p] == 'CP':
+                    A['fac'][n] = cmtf_nvecs(Z, n, R, eng_nv)
+                elif md.index(n) == 0:
+                    M = np.hstack([np.asarray(Xk, dtype=np.float64) for Xk in Z['object'][p]])
+                    A['fac'][n] = _leading_eigvecs(eng_nv.unfold_gram(M, 0), R)
+                elif md.index(n) == 1:
+                    A['DeltaB'][p] = rng.random((R, R))
+                    A['fac'][n] = []
+                    A['P'][p] = []
+                    A['mu_DeltaB'][p] = []
+                    for k in range(len(sz[n])):
+                        Xk = np.asarray(Z['object'][p][k], dtype=np.float64)
+                        A['fac'][n].append(_leading_eigvecs(eng_nv.unfold_gram(Xk, 1), R))
+                        A['P'][p].append(np.eye(sz[n][k], R))
+                        A['mu_DeltaB'][p].append(rng.random((sz[n][k], R)))
+                else:
+                    A['fac'][n] = np.ones((sz[n], R))
+                continue
             if Z['model'][p] == 'PAR2' and md.index(n) == 1:
                 A['DeltaB'][p] = rng.random((R, R))
                 A['fac'][n] = []

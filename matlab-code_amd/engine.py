@@ -95,6 +95,15 @@ class Engine:
         capi.check(self.lib.aoadmm_op_mttkrp(self.h, capi.dptr(X), X.ndim, dims, arr, R, int(n), prec, capi.dptr(out)))
         return out
 
+    def unfold_gram(self, X, n, precision='f64'):
+        """`Y = A*A'` with A the mode-n unfolding of X (0-based n), cmtf_nvecs.m:40-56."""
+        X = capi.as_f(X)
+        dims = (C.c_int64 * X.ndim)(*X.shape)
+        out = np.zeros((X.shape[n], X.shape[n]), order='F')
+        prec = capi.PREC_F32 if precision == 'f32' else capi.PREC_F64
+        capi.check(self.lib.aoadmm_op_unfold_gram(self.h, capi.dptr(X), X.ndim, dims, int(n), prec, capi.dptr(out)))
+        return out
+
     def gram(self, F):
         F = capi.as_f(F)
         out = np.zeros((F.shape[1], F.shape[1]), order='F')

@@ -128,6 +128,21 @@ mxArray* get_like(int field_id, int index, const mxArray* ref) {
 
 /* [Fac, out] = aoadmm_mex(Z, G, options)      (options.hip.device / .precision are optional) */
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+  // Y = aoadmm_mex('unfold_gram', X, n): Gram matrix of the mode-n unfolding (cmtf_nvecs.m:40-56), n 1-based
+  if (nrhs == 3 && mxIsChar(prhs[0])) {
+    if (str(prhs[0]) != "unfold_gram") mexErrMsgIdAndTxt("cmtf:hip:usage", "unknown operation '%s'", str(prhs[0]).c_str());
+    if (!g_ctx) { check(aoadmm_create(&g_ctx, 0)); mexAtExit(at_exit); }
+    const mxArray* X = prhs[1];
+    const int nd = (int)mxGetNumberOfDimensions(X);
+    const mwSize* d = mxGetDimensions(X);
+    int64_t dims[8];
+    for (int i = 0; i < nd && i < 8; ++i) dims[i] = (int64_t)d[i];
+    const int n = (int)mxGetScalar(prhs[2]) - 1;
+    if (nd < 2 || nd > 3 || n < 0 || n >= nd) mexErrMsgIdAndTxt("cmtf:hip:unsupported", "unfold_gram handles matrices and 3-way tensors");
+    plhs[0] = mxCreateDoubleMatrix((mwSize)dims[n], (mwSize)dims[n], mxREAL);
+    check(aoadmm_op_unfold_gram(g_ctx, mxGetDoubles(X), nd, dims, n, AOADMM_PREC_F64, mxGetDoubles(plhs[0])));
+    return;
+  }
   if (nrhs != 3 || nlhs > 2) mexErrMsgIdAndTxt("cmtf:hip:usage", "usage: [Fac,out] = aoadmm_mex(Z, G, options)");
   const mxArray *Z = prhs[0], *G = prhs[1], *opt = prhs[2];
   int device = 0, precision = AOADMM_PREC_F64;

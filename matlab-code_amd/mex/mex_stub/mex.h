@@ -31,6 +31,9 @@ size_t mxGetNumberOfElements(const mxArray*);
 char* mxArrayToString(const mxArray*);
 void mxFree(void*);
 double mxGetNaN(void);
+const mwSize* mxGetDimensions(const mxArray*);
+mwSize mxGetNumberOfDimensions(const mxArray*);
+bool mxIsChar(const mxArray*);
 void* mxGetData(const mxArray*);
 bool mxIsUint8(const mxArray*);
 mxArray* mxCreateDoubleMatrix(mwSize, mwSize, mxComplexity);

@@ -869,8 +869,26 @@ def cmtf_AOADMM(Z, alg_options=None, init='random', init_options=None, rng=None)
     return Zhat, Fac, G, out
 
 
+def _leading_eigvecs(Y, r):
+    """`[U,~] = eigs(Y, r, 'LM')` (cmtf_nvecs.m:58): eigenvectors of the r largest-magnitude eigenvalues; signs are
+    arbitrary (ARPACK's are too), so comparisons use the spanned subspace."""
+    w, V = np.linalg.eigh((Y + Y.T) / 2)
+    idx = np.argsort(-np.abs(w), kind='stable')[:r]
+    return V[:, idx]
+
+
+def cmtf_nvecs(Z, n, r):
+    """functions/cmtf_nvecs.m:1-58 (dense data): A = mode-n unfolding of the data set owning mode n, Y = A*A'."""
+    which_p = _which_p(Z)
+    p = which_p[n]
+    X = np.asarray(Z['object'][p], dtype=np.float64)
+    i = _modes0(Z, p).index(n)
+    A = np.moveaxis(X, i, 0).reshape(X.shape[i], -1)
+    return _leading_eigvecs(A @ A.T, r)
+
+
 def init_coupled_AOADMM_CMTF(Z, init_options, Delta=None, rng=None):
-    """functions/init_coupled_AOADMM_CMTF.m:1-174, random path (`nvecs = 0`).
+    """functions/init_coupled_AOADMM_CMTF.m:1-174 (random path, and the SVD-based path `nvecs = 1`, :50-73).
 
     `init_options['distr'][n]` is a callable `(rows, cols) -> ndarray`;
     MATLAB's `rand(...)` calls are drawn from `rng.random(...)` (numpy Generator).
@@ -879,8 +897,7 @@ def init_coupled_AOADMM_CMTF(Z, init_options, Delta=None, rng=None):
     """
     if rng is None:
         rng = np.random.default_rng(0)
-    if init_options.get('nvecs', 0):
-        raise NotImplementedError('nvecs initialisation (cmtf_nvecs.m) is out of scope (SURVEY 2.1)')
+    nvecs = bool(init_options.get('nvecs', 0))
     sz = Z['size']
     lambdas = init_options['lambdas_init']
     distr = init_options['distr']
@@ -901,6 +918,23 @@ def init_coupled_AOADMM_CMTF(Z, init_options, Delta=None, rng=None):
         md = _modes0(Z, p)
         R = len(lambdas[p])
         for n in md:
+            if nvecs:                                                           # :50-73
+                if Z['model'][p] == 'CP':
+                    A['fac'][n] = cmtf_nvecs(Z, n, R)
+                elif md.index(n) == 0:
+                    M = np.hstack([np.asarray(Xk, dtype=np.float64) for Xk in Z['object'][p]])
+                    A['fac'][n] = _leading_eigvecs(M @ M.T, R)
+                elif md.index(n) == 1:
+                    A['DeltaB'][p] = rng.random((R, R))
+                    A['fac'][n] = []; A['P'][p] = []; A['mu_DeltaB'][p] = []
+                    for k in range(len(sz[n])):
+                        Mk = np.asarray(Z['object'][p][k], dtype=np.float64).T
+                        A['fac'][n].append(_leading_eigvecs(Mk @ Mk.T, R))
+                        A['P'][p].append(np.eye(sz[n][k], R))
+                        A['mu_DeltaB'][p].append(rng.random((sz[n][k], R)))
+                else:
+                    A['fac'][n] = np.ones((sz[n], R))
+                continue
             if Z['model'][p] == 'PAR2' and md.index(n) == 1:                    # :75-86
                 A['DeltaB'][p] = rng.random((R, R))
                 A['fac'][n] = []; A['P'][p] = []; A['mu_DeltaB'][p] = []

@@ -102,3 +102,37 @@ def test_admm_constrained_only(eng, c):
     gf, gz, gm, its = eng.admm_constrained(A, Bsys, rho, c, fac, Zc, mu, 5, 0.0, 0.0)
     assert its == 5
     assert rel_fro(gf, f) < 1e-11 and rel_fro(gz, z) < 1e-11 and rel_fro(gm, m) < 1e-11
+
+
+@pytest.mark.parametrize('dims', [(37, 22, 19), (64, 64, 5), (130, 9, 70), (41, 33)])
+@pytest.mark.parametrize('prec,tol', [('f64', 1e-12), ('f32', 5e-6)])
+def test_unfold_gram(pkg, eng, dims, prec, tol):
+    """Y = X_(n) X_(n)' for every mode (cmtf_nvecs.m:40-56) against numpy."""
+    rng = np.random.default_rng(sum(dims))
+    X = rng.standard_normal(dims)
+    for n in range(len(dims)):
+        A = np.moveaxis(X, n, 0).reshape(dims[n], -1)
+        Y = eng.unfold_gram(X, n, precision=prec)
+        assert np.linalg.norm(Y - A @ A.T) / np.linalg.norm(A @ A.T) < tol
+
+
+def test_nvecs_initialisation(pkg, eng):
+    """init_options.nvecs = 1 (init_coupled_AOADMM_CMTF.m:50-73): the factors are the leading eigenvectors of the
+    unfolding Gram matrices; eigenvector signs are arbitrary, so the spanned subspaces are compared."""
+    from oracle import aoadmm as OA
+    from helpers import script1_model
+    rng = np.random.default_rng(71)
+    Z, io = script1_model(rng, dims=(20, 30, 40), K=6, Jk=30, noise=0.05)
+    io = dict(io, nvecs=1)
+    Go = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(3))
+    Gg = pkg.init_coupled_AOADMM_CMTF(Z, io, rng=np.random.default_rng(3), engine=eng)
+
+    def same_span(a, b):
+        return np.linalg.norm(a @ (a.T @ b) - b) < 1e-8 * np.linalg.norm(b)
+    for m, (fo, fg) in enumerate(zip(Go['fac'], Gg['fac'])):
+        if isinstance(fo, list):
+            assert all(same_span(x, y) for x, y in zip(fo, fg))
+        elif np.allclose(fo, 1.0):
+            assert np.allclose(fg, 1.0)                 # PARAFAC2 C mode: ones (:70-72)
+        else:
+            assert same_span(fo, fg), m
