@@ -1,0 +1,80 @@
+"""Fixtures of tests/golden/ (built by tests/golden/make_golden.py from the only data files the reference ships:
+functions_for_example_scripts/noisy_dataset.mat + gnd_factors.mat, the input and ground truth of
+example_script11_tPARAFAC2.m).
+
+* known answer: on that data set the script-11 model recovers the ground-truth factors (FMS > 0.98 for A and C) --
+  the one check in this repository whose expected value comes from the reference itself;
+* regression: the oracle reproduces the stored 40-iteration run (same init, tolerances 0);
+* GPU: the HIP path reproduces the same stored numbers (1e-8 relative Frobenius)."""
+import copy
+import importlib
+import itertools
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+from make_golden import script11_model, script11_options, unpack_G   # noqa: E402
+from oracle import aoadmm as OA                                      # noqa: E402
+from helpers import rel_fro                                          # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def data():
+    return np.load(os.path.join(HERE, 'golden', 'script11_data.npz'))
+
+
+@pytest.fixture(scope='module')
+def expected():
+    return np.load(os.path.join(HERE, 'golden', 'script11_expected.npz'))
+
+
+def fms(U, V):
+    """factor match score of two 3-column matrices, best permutation (Tensor Toolbox `score`, lambda_penalty false)"""
+    U = U / np.linalg.norm(U, axis=0)
+    V = V / np.linalg.norm(V, axis=0)
+    M = np.abs(U.T @ V)
+    return max(np.prod([M[i, p[i]] for i in range(3)]) for p in itertools.permutations(range(3)))
+
+
+def check_against_expected(Fac, out, expected, tol):
+    K = expected['out_fac1'].shape[0]
+    assert rel_fro(Fac['fac'][0], expected['out_fac0']) < tol
+    assert rel_fro(Fac['fac'][2], expected['out_fac2']) < tol
+    for k in range(K):
+        assert rel_fro(Fac['fac'][1][k], expected['out_fac1'][k]) < tol
+        assert rel_fro(Fac['P'][0][k], expected['out_P'][k]) < tol
+        assert rel_fro(Fac['constraint_fac'][1][k], expected['out_Z1'][k]) < tol
+    assert rel_fro(Fac['DeltaB'][0], expected['out_DeltaB']) < tol
+    assert np.allclose(out['func_val_conv'], expected['func_val_conv'], rtol=max(tol, 1e-9))
+    assert np.allclose(out['func_PAR2_coupl'], expected['func_PAR2_coupl'], rtol=1e-6, atol=1e-10)
+
+
+def test_oracle_reproduces_golden_run(data, expected):
+    Z = script11_model(data['dataset'])
+    G = unpack_G(expected, 'init_')
+    _, Fac, _, out = OA.cmtf_AOADMM(Z, alg_options=script11_options(40), init=copy.deepcopy(G))
+    check_against_expected(Fac, out, expected, 1e-10)
+
+
+def test_script11_known_answer_recovers_ground_truth(data, expected):
+    """example_script11_tPARAFAC2.m:160-164 evaluates FMS_A / FMS_C against gnd_factors.mat; with the script's own
+    constraints and ridge the oracle reaches > 0.98 within 300 outer iterations."""
+    Z = script11_model(data['dataset'])
+    G = unpack_G(expected, 'init_')
+    _, Fac, _, out = OA.cmtf_AOADMM(Z, alg_options=script11_options(300, tol0=False), init=copy.deepcopy(G))
+    assert fms(Fac['fac'][0], data['A']) > 0.98
+    assert fms(Fac['fac'][2], data['C']) > 0.98
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_run(data, expected):
+    pkg = importlib.import_module('matlab-code_amd')
+    Z = script11_model(data['dataset'])
+    G = unpack_G(expected, 'init_')
+    with pkg.Engine(0) as eng:
+        _, Fac, _, out = pkg.cmtf_AOADMM(Z, alg_options=script11_options(40), init=copy.deepcopy(G), engine=eng)
+    check_against_expected(Fac, out, expected, 1e-8)
