@@ -187,7 +187,9 @@ def main():
             'config': {'workload': 'cfg5: %dx%dx%d R=%d CP, mode1 TV(0.001), modes2-3 nonneg, %s tensor + fp64 solve, '
                                    'MaxInnerIters=5, tol=0' % (I, J, K, R, args.prec),
                        'sharding': 'mode-1 rows over %d GPU(s), factors replicated' % world,
-                       'tensor_passes_per_iter': round((launches + int(nl1.value)) / args.steps, 2)},
+                       'tensor_passes_per_iter': round((launches + int(nl1.value)) / args.steps, 2),
+                       'resident_copies': 'X(i,j,k) + mode-permuted X(j,k,i): 2 x %.0f GB per node'
+                                          % (I * J * K * (4.0 if args.prec == 'f32' else 8.0) / 1e9)},
             'mttkrp_mode1_gflops': flops_mttkrp / (mttkrp_ms * 1e-3) / 1e9,
             'mttkrp_mode1_ms': mttkrp_ms,
             'mttkrp_mfma_frac_f32_peak': flops_mttkrp / (mttkrp_ms * 1e-3) / 1e12 / (F32_MFMA_PEAK_TF * world),
@@ -201,7 +203,8 @@ def main():
                          'note': 'per rank; algorithmic bytes = local tensor block read once (s_X per entry) + T written once '
                                  '(s_X*R per unfolding row); traffic = FETCH_SIZE x2 + WRITE_SIZE of a separate rocprofv3 --pmc '
                                  'run (profiles/r01_pmc_contract16_f32.json)'},
-            'second_kernel': {'kernel': 'contract_lead16_f32 (leading-mode contraction, LDS-transposed; 1 of 3 tensor passes)',
+            'second_kernel': {'kernel': 'contract_lead16_f32 (leading-mode contraction, LDS-transposed): only used when the '
+                                        'mode-permuted second copy of the tensor is switched off or does not fit',
                               'launches': int(nl1.value),
                               'avg_launch_ms': (ms1.value / nl1.value) if nl1.value else None,
                               'achieved_GBps': (by1.value / nl1.value / (ms1.value / nl1.value * 1e-3) / 1e9) if nl1.value and ms1.value > 0 else None},

@@ -111,7 +111,10 @@ typedef struct aoadmm_options {
   double increase_factor_rhoBk;
   int32_t use_dimtree;                   /* engine option (options.hip.*): reuse partial
                                             contractions between modes; 1 = default */
-  int32_t reserved[7];
+  int32_t no_permuted_copy;              /* engine option: 1 = do not keep the second, mode-permuted resident copy of
+                                            3-way tensors (saves the tensor's size in HBM, mode-1 contractions then
+                                            use the LDS-transposed kernel); 0 = default */
+  int32_t reserved[6];
 } aoadmm_options;
 
 /* `out` struct of cmtf_fun_AOADMM.m:480-494.  Arrays are caller-allocated with

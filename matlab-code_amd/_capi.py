@@ -54,7 +54,8 @@ class Options(C.Structure):
         ('innerRelDualTol_coupl', C.c_double), ('innerRelDualTol_constr', C.c_double),
         ('bsum', C.c_int32), ('bsum_weight', C.c_double),
         ('iter_start_PAR2Bkconstraint', C.c_int32), ('has_increase_factor_rhoBk', C.c_int32),
-        ('increase_factor_rhoBk', C.c_double), ('use_dimtree', C.c_int32), ('reserved', C.c_int32 * 7),
+        ('increase_factor_rhoBk', C.c_double), ('use_dimtree', C.c_int32), ('no_permuted_copy', C.c_int32),
+        ('reserved', C.c_int32 * 6),
     ]
 
 

@@ -42,6 +42,9 @@ void reg_value(double* slot, int type, double p0, const double* X, int64_t rows,
 // uniform [0,1) fill (device RNG; used by tests/bench for factor initialisation on device)
 void fill_uniform(double* x, int64_t n, uint64_t seed, hipStream_t s);
 
+// Xp(j,k,i) = X(i,j,k), leading dimensions Ip (X) and Jp (Xp); padding rows of Xp are written as zeros
+void permute_231(const void* X, void* Xp, int prec, int64_t I, int64_t Ip, int64_t J, int64_t Jp, int64_t K,
+                 hipStream_t s);
 // Y = X_(n) X_(n)' of a resident dense block (cmtf_nvecs.m:56): row a of the unfolding at X + a*sa, reduction
 // over t1 < n1 (stride s1) x t2 < n2 (stride s2); Y is n x n column-major fp64.
 struct UnfoldGramArgs {

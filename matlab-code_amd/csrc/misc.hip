@@ -246,6 +246,39 @@ void reg_value(double* slot, int type, double p0, const double* X, int64_t rows,
 }
 
 // ---------------------------------------------------------------------------
+// Xp(j, k, i) = X(i, j, k): second resident copy of a 3-way tensor with the first mode moved to the back, so that
+// the contraction over mode 1 streams like the trailing-mode contractions instead of needing the LDS-transposed
+// kernel.  32 x 32 tiles through LDS per k; Xp's leading dimension J is padded to Jp (padding written as zeros).
+template <typename T>
+__global__ __launch_bounds__(256) void permute_231_k(const T* __restrict__ X, T* __restrict__ Xp, int64_t I,
+                                                    int64_t Ip, int64_t J, int64_t Jp, int64_t K) {
+  __shared__ T tile[32][33];
+  const int64_t k = blockIdx.z;
+  const int64_t i0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+  const T* Xk = X + Ip * J * k;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t i = i0 + tx, j = j0 + ty + 8 * q;
+    tile[ty + 8 * q][tx] = (i < I && j < J) ? Xk[i + Ip * j] : (T)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t j = j0 + tx, i = i0 + ty + 8 * q;
+    if (j < Jp && i < I) Xp[j + Jp * (k + K * i)] = tile[tx][ty + 8 * q];   // j >= J: zeros from the load guard
+  }
+}
+void permute_231(const void* X, void* Xp, int prec, int64_t I, int64_t Ip, int64_t J, int64_t Jp, int64_t K,
+                 hipStream_t s) {
+  AO_REQUIRE(K <= 65535 && cdiv(Jp, 32) <= 65535, "permute_231: mode too long for one launch");
+  const dim3 grid((unsigned)cdiv(I, 32), (unsigned)cdiv(Jp, 32), (unsigned)K);
+  if (prec == AOADMM_PREC_F32) permute_231_k<float><<<grid, 256, 0, s>>>((const float*)X, (float*)Xp, I, Ip, J, Jp, K);
+  else permute_231_k<double><<<grid, 256, 0, s>>>((const double*)X, (double*)Xp, I, Ip, J, Jp, K);
+  AO_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
 // Gram of a mode-n unfolding, Y = X_(n) X_(n)'  (functions/cmtf_nvecs.m:56: `Y = A*A'` for the SVD-based
 // initialisation; the leading eigenvectors are taken on the host).  Unfolding row a sits at X + a*sa; the
 // reduction runs over t1 < n1 (stride s1) and t2 < n2 (stride s2).  64 x 64 output tiles, 16 reduction

@@ -28,6 +28,11 @@ struct FactorRef {
 struct CpBlock {
   DenseTensor X;       // natural layout, first dimension padded
   DenseTensor Xt;      // matrices only: transposed copy (second mode contiguous)
+  // 3-way tensors: optional second copy Xp(j,k,i) = X(i,j,k) (leading dimension Jp), built on first use, so that
+  // the pass that contracts mode 1 streams like the others (the tensor's size again in HBM; 288 GB per GPU)
+  DevBuf Xp;
+  int64_t Jp = 0;
+  bool has_xp = false, xp_refused = false;
   int nd = 0;
   int64_t dims[8] = {0};   // local sizes (dims[0] = local rows when sharded)
   int64_t full0 = 0;       // global size of the first mode
@@ -169,6 +174,7 @@ class Engine {
   // MTTKRP of a dense block against factors (device), result scale*mttkrp into out (ld = ldOut)
   void ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int R, bool use_cache, const int* update_seq,
                           int nseq);
+  bool ensure_permuted_copy(CpBlock& b);
   void prefetch_next_contraction(const aoadmm_options& opt);
   void block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
                     int64_t ldOut, bool use_cache, const int* update_seq, int nseq);
@@ -213,6 +219,7 @@ class Engine {
   DevBuf slots_;         // objective scalars
   DevBuf redws_;         // reduction workspace
   DevBuf emws_;          // EM pass partial sums
+  bool allow_xp_ = true;  // options.hip.no_permuted_copy
   DevBuf atbws_;
   DevBuf staging_;
   KernelStats kstats_[2];   // [0] streaming contraction, [1] leading-mode contraction

@@ -377,6 +377,7 @@ void Engine::block_upload(CpBlock& b, int nd, const int64_t* dims, const double*
   }
   b.has_data = true;
   b.cached_mode = -1;
+  b.has_xp = false; b.xp_refused = false;
 }
 
 void Engine::tensor_upload(int p, const double* data, int prec, int64_t row0, int64_t local_rows) {
@@ -481,6 +482,7 @@ void Engine::tensor_synth(int p, int rank, uint64_t seed, double noise, int prec
   AO_HIP(hipStreamSynchronize(stream_));
   b.has_data = true;
   b.cached_mode = -1;
+  b.has_xp = false; b.xp_refused = false;
   t.normsq_valid = false;
 }
 
@@ -514,6 +516,7 @@ void Engine::tensor_mask_upload(int p, const uint8_t* mask) {
   }
   AO_HIP(hipStreamSynchronize(stream_));
   b.has_mask = true;
+  if (b.has_xp) { b.Xp.release(); b.has_xp = false; b.cached_mode = -1; }    // the imputation would have to update it too
   t.normsq_valid = false;
 }
 
@@ -746,6 +749,26 @@ static int next_update_distance(int pos, int c, const int* seq, int n) {
 
 // Tensor pass for a 3-way block: makes b.T hold the partial contraction that serves an MTTKRP for tensor
 // position `pos` (a cached one is reused while its factor is unchanged).
+// Second resident copy with the first mode last (see CpBlock::Xp).  Built lazily; refused when the mask of an EM
+// problem would have to be kept in sync, when the caller opted out, or when HBM cannot hold it.
+bool Engine::ensure_permuted_copy(CpBlock& b) {
+  if (b.has_xp) return true;
+  if (b.xp_refused || !allow_xp_ || b.has_mask || b.nd != 3) return false;
+  const int64_t I = b.dims[0], J = b.dims[1], K = b.dims[2];
+  const int64_t Jp = round_up(J, b.X.prec == AOADMM_PREC_F32 ? 4 : 2);
+  const size_t bytes = (size_t)Jp * K * I * b.X.elem_size();
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (size_t)(4ull << 30) || K > 65535) {
+    b.xp_refused = true;
+    return false;
+  }
+  b.Xp.alloc(bytes);
+  b.Jp = Jp;
+  permute_231(b.X.data.p, b.Xp.p, b.X.prec, I, b.X.pad0, J, Jp, K, stream_);
+  b.has_xp = true;
+  return true;
+}
+
 void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int R, bool use_cache,
                                 const int* update_seq, int nseq) {
   const int prec = b.X.prec;
@@ -760,7 +783,8 @@ void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int 
   for (int cand = 2; cand >= 0; --cand) {
     if (cand == pos) continue;
     static const bool force_lead = getenv("AOADMM_FORCE_LEAD") != nullptr;   // development switch (tools/perf_mttkrp.py)
-    if (cand == 0 && !(prec == AOADMM_PREC_F32 && (use_cache || force_lead))) continue;
+    // contracting mode 1 needs the permuted copy (any precision) or the LDS-transposed kernel (fp32 only)
+    if (cand == 0 && !((use_cache || force_lead) && (prec == AOADMM_PREC_F32 || ensure_permuted_copy(b)))) continue;
     if (cand != 0 && force_lead && prec == AOADMM_PREC_F32 && pos != 0) continue;
     const int dist = next_update_distance(pos, cand, update_seq, nseq);
     if (dist > best) { best = dist; c = cand; }
@@ -769,9 +793,19 @@ void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int 
   const double* Fc = facs[c].p;
   if (c == 2) pl = make_plan(1, 0, Ip * J, Ip * J, K, R, prec);
   else if (c == 1) pl = make_plan(K, Ip * J, Ip, Ip, J, R, prec);
-  else { pl = make_lead_plan(J * K, Ip, I, R); Fc = facs[0].p + (comm_ ? b.row0 : 0); }
+  else {
+    Fc = facs[0].p + (comm_ ? b.row0 : 0);
+    static const bool force_ldskernel = getenv("AOADMM_LEAD_KERNEL") != nullptr;   // development switch
+    if (!force_ldskernel && ensure_permuted_copy(b)) {
+      // Xp(j,k,i): mode 1 is the trailing index with stride Jp*K -> the register-streaming contraction
+      pl = make_plan(1, 0, b.Jp * K, b.Jp * K, I, R, prec);
+      pl.on_xp = true;
+    } else {
+      pl = make_lead_plan(J * K, Ip, I, R);
+    }
+  }
   b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
-  timed_contract(b.X.data.p, prec, pl, Fc, facs[c].ld, b.frag.p, b.T.p);
+  timed_contract(pl.on_xp ? b.Xp.p : b.X.data.p, prec, pl, Fc, facs[c].ld, b.frag.p, b.T.p);
   b.cached_mode = c; b.cached_version = facs[c].version; b.plan = pl;
 }
 
@@ -837,7 +871,7 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
     const ContractPlan& pl = b.plan;
     // T rows are (a + Apad*bb) with (a, bb) the two uncontracted modes in tensor order
     const int ia = c == 0 ? 1 : 0, ib = c == 2 ? 1 : 2;
-    const int64_t An = ia == 0 ? I : J, Apad = ia == 0 ? Ip : J;
+    const int64_t An = ia == 0 ? I : J, Apad = ia == 0 ? Ip : (pl.on_xp ? b.Jp : J);
     const int64_t Bn = ib == 1 ? J : K;
     const double* Fa = ia == 0 ? F0 : facs[1].p;
     if (pos == ia) {
@@ -1299,6 +1333,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   AO_REQUIRE(out != nullptr, "null result");
   AO_REQUIRE(opt.MaxOuterIters >= 0 && opt.MaxInnerIters >= 1, "bad iteration limits");
   AO_HIP(hipSetDevice(device_));
+  allow_xp_ = opt.no_permuted_copy == 0;
   for (int p = 0; p < n_tensors_; ++p) {
     AO_REQUIRE(tensors_[p].blk.has_data, "tensor %d has no data (Z.object{%d})", p, p + 1);
     AO_REQUIRE(tensors_[p].nmodes <= 3, "tensors of order > 3 are not in the device path yet");

@@ -224,6 +224,7 @@ def _make_options(alg_options):
         o.increase_factor_rhoBk = float(alg_options['increase_factor_rhoBk'])
     hip = alg_options.get('hip', {})
     o.use_dimtree = int(hip.get('use_dimtree', 1))
+    o.no_permuted_copy = int(hip.get('no_permuted_copy', 0))
     return o
 
 

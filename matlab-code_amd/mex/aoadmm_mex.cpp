@@ -297,6 +297,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     o.increase_factor_rhoBk = mxGetScalar(f);
   }
   o.use_dimtree = 1;
+  if (const mxArray* hip = field(opt, "hip", false))
+    if (const mxArray* f = field(hip, "no_permuted_copy", false)) o.no_permuted_copy = (int)mxGetScalar(f);
 
   // ---- solve
   const int n = o.MaxOuterIters + 1;
