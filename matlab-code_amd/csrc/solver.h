@@ -117,7 +117,8 @@ struct TensorInfo {
 struct CouplingInfo {
   int type = -1;
   std::vector<int> modes;
-  DevBuf Delta, DeltaOld, BB, AA, LAA, dD, tmp, coef;
+  DevBuf Delta, DeltaOld, BB, AA, LAA, dD, tmp, coef, rho_ptrs;
+  std::vector<const double*> rho_ptrs_host;
   int64_t rows = 0, cols = 0;
   bool has_state = false;
 };

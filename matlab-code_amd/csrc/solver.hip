@@ -565,11 +565,9 @@ void Engine::em_pass_enqueue(int p, int update) {
     at.X = b.Xt.data.p; at.mask = b.maskT.as<uint8_t>();
     at.A = m1.fac.d(); at.ldA = m1.rows; at.B = m0.fac.d() + (comm_ ? b.row0 : 0); at.ldB = m0.rows;
     at.I = b.dims[1]; at.Ipad = b.Xt.pad0; at.J = b.dims[0];
-    emws_.ensure(em_cp_ws_bytes(at.Ipad, 1) + 64);
-    DevBuf scratch4;
-    scratch4.alloc(4 * sizeof(double));
-    em_cp_pass(at, b.Xt.prec, emws_.d(), scratch4.d(), stream_);
-    AO_HIP(hipStreamSynchronize(stream_));
+    const size_t wsb = em_cp_ws_bytes(at.Ipad, 1);
+    emws_.ensure(wsb + 64);
+    em_cp_pass(at, b.Xt.prec, emws_.d(), emws_.d() + wsb / sizeof(double), stream_);   // statistics to a scratch tail
   }
   allreduce(em_slot(p), 4);
   if (update) b.cached_mode = -1;                    // the data changed: cached partial contractions are stale
@@ -1086,11 +1084,15 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
   // reset the loop control (the per-mode sys_build calls reset their own blocks)
   ctl_reset(ctl, stream_);
   // per-outer-iteration constants
-  DevBuf rho_ptrs;
   std::vector<const double*> hp(n);
   for (int j = 0; j < n; ++j) hp[j] = modes_[ci.modes[j]].rho.d();
-  rho_ptrs.alloc(n * sizeof(double*));
-  AO_HIP(hipMemcpyAsync(rho_ptrs.p, hp.data(), n * sizeof(double*), hipMemcpyHostToDevice, stream_));
+  DevBuf& rho_ptrs = ci.rho_ptrs;                     // pointers never change once the work buffers exist
+  if (ci.rho_ptrs_host != hp) {
+    rho_ptrs.ensure(8 * sizeof(double*));
+    AO_HIP(hipMemcpyAsync(rho_ptrs.p, hp.data(), n * sizeof(double*), hipMemcpyHostToDevice, stream_));
+    AO_HIP(hipStreamSynchronize(stream_));            // hp is a local
+    ci.rho_ptrs_host = hp;
+  }
   const double* rho_last = hp[n - 1];                 // type 5: rhoC = mean(rho{mm}) with the stale loop variable (:1032)
   if (ty == 0 || ty == 1 || ty == 2) {
     coupling_coefs_k<<<1, 64, 0, stream_>>>(ci.coef.d(), rho_ptrs.as<const double*>(), n);
@@ -1229,7 +1231,6 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
     }
     admm_finalize_generic(fa, ctl, stream_);
   }
-  AO_HIP(hipStreamSynchronize(stream_));     // rho_ptrs goes out of scope
 }
 
 // ---------------------------------------------------------------------------

@@ -129,3 +129,21 @@ def test_em_missing_data_recovers_noise_free_entries():
     # f_tensors is the observed-entry residual
     direct = np.sum(((Z['object'][0] - M) ** 2)[mask])
     assert abs(out['f_tensors'] - direct) < 1e-10
+
+
+@pytest.mark.parametrize('ctype', [1, 2, 3, 5])
+def test_transformed_couplings_known_answer(ctype):
+    """Noise-free data generated WITH the coupling relation (example_script5 / 13 families): the restatement of
+    coupling types 1, 2, 3, 5 (cmtf_fun_AOADMM.m:698-901, :986-1075) must fit both tensors and satisfy
+    Tf(C) = Sd(Delta) at the solution -- the known answer those scripts imply."""
+    import copy
+    from helpers import transformed_coupling_model, options
+    rng = np.random.default_rng(80 + ctype)
+    Z, io = transformed_coupling_model(rng, ctype, noise=0.0)
+    Delta = [np.zeros((25, 4))] if ctype == 5 else None
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, Delta=Delta, rng=np.random.default_rng(1))
+    opt = options(MaxOuterIters=1500, MaxInnerIters=5, AbsFuncTol=1e-12, OuterRelTol=1e-10,
+                  innerRelPrTol_coupl=1e-5, innerRelPrTol_constr=1e-5, innerRelDualTol_coupl=1e-5, innerRelDualTol_constr=1e-5)
+    _, Fac, _, out = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
+    assert out['f_tensors'] < 1e-4, out['f_tensors']          # both tensors fitted (||X|| = 1 each, weights 0.5)
+    assert out['f_couplings'] < 1e-2, out['f_couplings']      # relative coupling gap (:1303-1329)
