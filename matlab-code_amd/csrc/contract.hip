@@ -1041,7 +1041,7 @@ __device__ __forceinline__ void fma_vec(double (&acc)[VEC], const TT* __restrict
 template <typename TT, int VEC>
 __global__ void reduce_inner_k(const TT* __restrict__ T, int nchunk, int64_t trows, int64_t A, int64_t Apad, int R,
                                const double* __restrict__ FaT, double scale, double* __restrict__ out,
-                               int64_t ldOut) {
+                               int64_t ldOut, int rowmajor) {
   extern __shared__ double sh[];                      // blockDim * VEC
   const int64_t b = blockIdx.x;
   const int t = threadIdx.x;
@@ -1067,7 +1067,8 @@ __global__ void reduce_inner_k(const TT* __restrict__ T, int nchunk, int64_t tro
     const int nA = blockDim.x * VEC / R;
     double tot = 0.0;
     for (int i = 0; i < nA; ++i) tot += sh[i * R + t];
-    out[b + ldOut * t] = scale * tot;
+    if (rowmajor) out[b * R + t] = scale * tot;       // T layout [b][r] for a further fold (N-way tensors)
+    else out[b + ldOut * t] = scale * tot;
   }
 }
 
@@ -1075,27 +1076,29 @@ size_t reduce_factor_scratch_bytes(int64_t rows, int R) { return (size_t)rows * 
 
 template <typename TT, int VEC>
 static void launch_inner_t(const void* T, int nchunk, int64_t trows, int64_t A, int64_t Apad, int64_t B, int R,
-                           const double* FaT, double scale, double* out, int64_t ldOut, hipStream_t s) {
+                           const double* FaT, double scale, double* out, int64_t ldOut, hipStream_t s, int rowmajor) {
   const int rq = R / VEC;                             // threads per row of T
   int threads = 256 / rq * rq;
   if (threads < rq) threads = rq;
   if (threads * VEC < R) threads = (R + VEC - 1) / VEC;
   reduce_inner_k<TT, VEC><<<(unsigned)B, threads, (size_t)threads * VEC * sizeof(double), s>>>(
-      (const TT*)T, nchunk, trows, A, Apad, R, FaT, scale, out, ldOut);
+      (const TT*)T, nchunk, trows, A, Apad, R, FaT, scale, out, ldOut, rowmajor);
 }
 
 void launch_reduce_inner(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
                          int64_t B, int R, const double* Fa, int64_t ldFa, double scale,
-                         double* out, int64_t ldOut, double* ft_scratch, hipStream_t s, const double* FaT) {
+                         double* out, int64_t ldOut, double* ft_scratch, hipStream_t s, const double* FaT,
+                         int rowmajor_out) {
+  AO_REQUIRE((int64_t)B <= 2147483647ll, "reduce_inner: too many output rows for one launch");
   if (FaT) ft_scratch = const_cast<double*>(FaT);    // row-major copy already maintained by the caller
   else factor_rowmajor(Fa, ldFa, A, R, ft_scratch, s);
   // 16-byte loads need every slab (Apad*R elements) and every chunk (trows*R) to start 16-byte aligned
   if (tprec == AOADMM_PREC_F32) {
-    if (R % 4 == 0) launch_inner_t<float, 4>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s);
-    else launch_inner_t<float, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s);
+    if (R % 4 == 0) launch_inner_t<float, 4>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s, rowmajor_out);
+    else launch_inner_t<float, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s, rowmajor_out);
   } else {
-    if (R % 2 == 0) launch_inner_t<double, 2>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s);
-    else launch_inner_t<double, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s);
+    if (R % 2 == 0) launch_inner_t<double, 2>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s, rowmajor_out);
+    else launch_inner_t<double, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s, rowmajor_out);
   }
   AO_KERNEL_CHECK();
 }
@@ -1163,7 +1166,7 @@ __global__ void reduce_outer_k(const TT* __restrict__ T, int nchunk, int64_t tro
 }
 
 __global__ void reduce_outer_fin(const double* __restrict__ part, int SB, int64_t A, int R, double scale,
-                                 double* __restrict__ out, int64_t ldOut) {
+                                 double* __restrict__ out, int64_t ldOut, int rowmajor) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= A * R) return;
   const int64_t a = idx / R;
@@ -1175,7 +1178,8 @@ __global__ void reduce_outer_fin(const double* __restrict__ part, int SB, int64_
     t1 += part[(int64_t)(s + 1) * A * R + idx];
   }
   if (s < SB) t0 += part[(int64_t)s * A * R + idx];
-  out[a + ldOut * r] = scale * (t0 + t1);
+  if (rowmajor) out[idx] = scale * (t0 + t1);         // T layout [a][r] for a further fold (N-way tensors)
+  else out[a + ldOut * r] = scale * (t0 + t1);
 }
 
 template <typename TT, int VEC>
@@ -1192,7 +1196,7 @@ static void launch_outer_t(const void* T, int nchunk, int64_t trows, int64_t A, 
 void launch_reduce_outer(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
                          int64_t B, int R, const double* Fb, int64_t ldFb, double scale,
                          double* out, int64_t ldOut, double* scratch, double* ft_scratch, hipStream_t s,
-                         const double* FbT) {
+                         const double* FbT, int rowmajor_out) {
   if (FbT) ft_scratch = const_cast<double*>(FbT);
   else factor_rowmajor(Fb, ldFb, B, R, ft_scratch, s);
   int SB = 1;
@@ -1205,7 +1209,7 @@ void launch_reduce_outer(const void* T, int tprec, int nchunk, int64_t trows, in
     else launch_outer_t<double, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s);
   }
   AO_KERNEL_CHECK();
-  reduce_outer_fin<<<(unsigned)cdiv(A * R, 256), 256, 0, s>>>(scratch, SB, A, R, scale, out, ldOut);
+  reduce_outer_fin<<<(unsigned)cdiv(A * R, 256), 256, 0, s>>>(scratch, SB, A, R, scale, out, ldOut, rowmajor_out);
   AO_KERNEL_CHECK();
 }
 

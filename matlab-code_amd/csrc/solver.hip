@@ -885,10 +885,65 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
                           ldOut, b.ft.d(), stream_, FaT);
     }
   } else {
-    // N-way (N > 3): contract the last mode (or the one before it when pos is last), then fold the
-    // remaining trailing modes one by one with reduce_outer, finally reduce over the leading modes
-    // against their materialised Khatri-Rao product.
-    throw Error(AOADMM_ERR_UNSUPPORTED, "tensors of order > 3 are not in the device path yet");
+    // N-way (N > 3): contract the last mode (the one before it when pos is last) on the matrix cores with all
+    // leading modes merged into the unfolding row, then fold the remaining modes one at a time over T: trailing
+    // modes with reduce_outer (down to pos), leading modes with reduce_inner (up to pos), each fold leaving a
+    // smaller T in the same [row][r] layout (fp64).  No partial-contraction reuse for these: N passes per iteration.
+    const int N = b.nd;
+    const int c = pos == N - 1 ? N - 2 : N - 1;
+    int64_t lead = Ip;                                  // merged size of the modes before c (first one padded)
+    for (int m = 1; m < c; ++m) lead *= b.dims[m];
+    ContractPlan pl = (c == N - 1) ? make_plan(1, 0, lead, lead, b.dims[c], R, prec)
+                                   : make_plan(b.dims[N - 1], lead * b.dims[c], lead, lead, b.dims[c], R, prec);
+    b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
+    timed_contract(b.X.data.p, prec, pl, c == 0 ? F0 : facs[c].p, facs[c].ld, b.frag.p, b.T.p);
+    // remaining modes in memory order, with their padded extents inside T
+    int rem[8], nrem = 0;
+    int64_t ext[8];
+    for (int m = 0; m < N; ++m)
+      if (m != c) { rem[nrem] = m; ext[nrem] = m == 0 ? Ip : b.dims[m]; ++nrem; }
+    const void* Tin = b.T.p;
+    int tprec = pl.tprec, nchunk = pl.nchunk;
+    int64_t trows = pl.trows();
+    int flip = 0;
+    auto tbuf = [&](int64_t rows) {
+      DevBuf& d = flip ? b.tmpB : b.tmpA;
+      flip ^= 1;
+      d.ensure((size_t)rows * R * sizeof(double));
+      return d.d();
+    };
+    // fold trailing modes above pos (last remaining mode first)
+    while (nrem > 1 && rem[nrem - 1] != pos) {
+      const int mb = rem[nrem - 1];
+      int64_t Arows = 1;
+      for (int q = 0; q < nrem - 1; ++q) Arows *= ext[q];
+      const bool last = nrem == 2;                      // after this fold only `pos` remains (it is rem[0])
+      double* dst = last ? out_local : tbuf(Arows);
+      const int64_t An = last ? (rem[0] == 0 ? I : b.dims[rem[0]]) : Arows;
+      b.scratch.ensure(reduce_outer_scratch_bytes(An, b.dims[mb], R));
+      b.ft.ensure(reduce_factor_scratch_bytes(b.dims[mb], R));
+      launch_reduce_outer(Tin, tprec, nchunk, trows, An, Arows, b.dims[mb], R, facs[mb].p, facs[mb].ld,
+                          last ? scale : 1.0, dst, last ? ldOut : 0, b.scratch.d(), b.ft.d(), stream_, nullptr, last ? 0 : 1);
+      if (last) { nrem = 1; break; }
+      Tin = dst; tprec = AOADMM_PREC_F64; nchunk = 1; trows = Arows;
+      --nrem;
+    }
+    // fold leading modes below pos (first remaining mode first)
+    while (nrem > 1) {
+      const int ma = rem[0];
+      int64_t Brows = 1;
+      for (int q = 1; q < nrem; ++q) Brows *= ext[q];
+      const bool last = nrem == 2;                      // after this fold only `pos` remains (it is rem[1])
+      double* dst = last ? out_local : tbuf(Brows);
+      const int64_t An = ma == 0 ? I : b.dims[ma];
+      b.ft.ensure(reduce_factor_scratch_bytes(An, R));
+      launch_reduce_inner(Tin, tprec, nchunk, trows, An, ext[0], Brows, R, ma == 0 ? F0 : facs[ma].p, facs[ma].ld,
+                          last ? scale : 1.0, dst, last ? ldOut : 0, b.ft.d(), stream_, nullptr, last ? 0 : 1);
+      Tin = dst; tprec = AOADMM_PREC_F64; nchunk = 1; trows = Brows;
+      for (int q = 0; q + 1 < nrem; ++q) { rem[q] = rem[q + 1]; ext[q] = ext[q + 1]; }
+      --nrem;
+    }
+    b.cached_mode = -1;
   }
   if (sharded) {
     if (ldOut == out_rows_full) allreduce(out, out_rows_full * R);
@@ -1337,7 +1392,6 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   allow_xp_ = opt.no_permuted_copy == 0;
   for (int p = 0; p < n_tensors_; ++p) {
     AO_REQUIRE(tensors_[p].blk.has_data, "tensor %d has no data (Z.object{%d})", p, p + 1);
-    AO_REQUIRE(tensors_[p].nmodes <= 3, "tensors of order > 3 are not in the device path yet");
   }
   for (int m = 0; m < n_modes_; ++m) {
     ModeInfo& mi = modes_[m];

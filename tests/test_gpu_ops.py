@@ -136,3 +136,17 @@ def test_nvecs_initialisation(pkg, eng):
             assert np.allclose(fg, 1.0)                 # PARAFAC2 C mode: ones (:70-72)
         else:
             assert same_span(fo, fg), m
+
+
+@pytest.mark.parametrize('dims', [(9, 7, 6, 5), (13, 4, 6, 3, 5), (34, 3, 2, 17)])
+@pytest.mark.parametrize('prec,tol', [('f64', 1e-12), ('f32', 3e-6)])
+def test_mttkrp_nway(pkg, eng, dims, prec, tol):
+    """Tensors of order > 3 (the toolbox mttkrp is N-way): one matrix-core contraction + successive folds over T."""
+    rng = np.random.default_rng(len(dims) + sum(dims))
+    X = rng.standard_normal(dims)
+    R = 4
+    U = [rng.standard_normal((n, R)) for n in dims]
+    for n in range(len(dims)):
+        ref = o_mttkrp(X, U, n)
+        got = eng.mttkrp(X, U, n, precision=prec)
+        assert rel_fro(got, ref) < tol, (n, rel_fro(got, ref))

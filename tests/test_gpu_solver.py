@@ -291,3 +291,10 @@ def test_transformed_couplings(pkg, eng, ctype):
     # type 5: init_coupled_AOADMM_CMTF.m:160-164 sizes coupling_fac from the Delta it is handed
     Delta = [np.zeros((25, 4))] if ctype == 5 else None
     compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=12), Delta=Delta))
+
+
+def test_cp_four_way(pkg, eng):
+    """A 4-way CP block through the solver (no example script uses one, the reference API allows it)."""
+    rng = np.random.default_rng(91)
+    Z, io, _ = cp_model((12, 9, 8, 7), 3, rng, [('non-negativity',), None, ('l2-ball', 1.0), ('non-negativity',)])
+    compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=10)))
