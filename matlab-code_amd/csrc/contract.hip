@@ -4,19 +4,22 @@
 // functions/cmtf_fun_AOADMM.m:97, third-party Tensor Toolbox).  Here it is
 // split into
 //   (1) one streaming pass over the tensor that contracts ONE mode with its
-//       factor matrix on the matrix cores (contract_f32 / contract_f64), giving
-//       T[m][r], and
+//       factor matrix on the matrix cores (contract16_f32 / contract_f64; the
+//       LDS-transposed contract_lead16_f32 when the contracted mode is the
+//       contiguous one and no mode-permuted copy exists), giving T[m][r], and
 //   (2) a small elementwise-multiply-and-reduce over T (reduce_inner / _outer).
 // (1) reads every tensor element exactly once with 16-byte coalesced loads
 // straight into MFMA operand registers (the unfolding's row index is the
-// contiguous one, so no LDS staging is needed); T is ~R*8/(C*s) of the tensor
+// contiguous one, so no LDS staging is needed); T is ~R/C of the tensor
 // bytes.  T is reusable for two modes (dimension tree), which is what cuts
-// the tensor reads per outer iteration from 3 to 2.
+// the tensor reads per outer iteration from 3 to 1.5.
 //
-// f32: v_mfma_f32_32x32x2_f32, lane l holds A[row l&31][k=l>>5], B[k=l>>5][col l&31];
-//      a lane's float4 load gives rows 4*(l&31)+v (v=0..3) of column k, i.e. four
-//      MFMA row tiles {4*rho+v}.  f64: v_mfma_f64_16x16x4_f64, lane l holds
-//      A[row l&15][k=l>>4]; a double2 load gives rows 2*(l&15)+v.
+// f32: v_mfma_f32_16x16x4_f32, lane l holds A[row l&15][k=l>>4], B[k=l>>4][col l&15];
+//      a lane's float4 load gives rows 4*(l&15)+v (v=0..3) of column k, i.e. four
+//      MFMA row tiles.  f64: v_mfma_f64_16x16x4_f64, same operand map; a double2 load
+//      gives rows 2*(l&15)+v.  (A first version used v_mfma_f32_32x32x2_f32: at R = 20 it
+//      issues 32 columns of matrix work per entry and ran 5.8 ms per 2000^3 pass against
+//      5.2 ms for 16 MFMA columns + 4 on the vector pipe.)
 #include "contract.h"
 
 #include <algorithm>
@@ -25,7 +28,6 @@
 namespace aoadmm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -35,22 +37,6 @@ static constexpr int kGroup = 8;          // reduction columns per pipeline stag
 // ---------------------------------------------------------------------------
 // operand packing: factor matrix (C x R, fp64 col-major) -> MFMA B fragments
 // ---------------------------------------------------------------------------
-// f32 layout: frag[nt][g][lane][s], value F[8g + 2s + (lane>>5)][32nt + (lane&31)]
-__global__ void pack_frag_f32(const double* __restrict__ F, int64_t ldF, int64_t C, int R, int NT,
-                              int64_t Cg, float* __restrict__ frag) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over nt*Cg*64*4
-  int64_t total = (int64_t)NT * Cg * 256;
-  if (idx >= total) return;
-  int s = idx & 3;
-  int lane = (idx >> 2) & 63;
-  int64_t g = (idx >> 8) % Cg;
-  int nt = (int)((idx >> 8) / Cg);
-  int64_t c = 8 * g + 2 * s + (lane >> 5);
-  int r = 32 * nt + (lane & 31);
-  float v = 0.f;
-  if (c < C && r < R) v = (float)F[c + ldF * r];
-  frag[idx] = v;
-}
 // f64 layout: frag[nt][g][lane][e], value F[8g + 4e + (lane>>4)][16nt + (lane&15)]
 __global__ void pack_frag_f64(const double* __restrict__ F, int64_t ldF, int64_t C, int R, int NT,
                               int64_t Cg, double* __restrict__ frag) {
@@ -68,9 +54,7 @@ __global__ void pack_frag_f64(const double* __restrict__ F, int64_t ldF, int64_t
   frag[idx] = v;
 }
 
-// ---------------------------------------------------------------------------
-// f32 contraction
-// ---------------------------------------------------------------------------
+// arguments of the register-streaming contractions (contract16_f32, contract_f64)
 struct KArgs {
   const void* X;
   const void* frag;
@@ -78,126 +62,6 @@ struct KArgs {
   int64_t tiles_per_batch, ntiles, batch_stride, M, ld, C, Cg, trows;
   int groups_per_chunk, R;
 };
-
-template <int NT, int SP>
-__global__ __launch_bounds__(256) void contract_f32(KArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wt >= a.ntiles) return;                       // wave-uniform
-  const int chunk = blockIdx.y;
-  const int64_t b = wt / a.tiles_per_batch;
-  const int64_t m0 = (wt - b * a.tiles_per_batch) * kTileRows;
-  const int r4 = lane & 31, h = lane >> 5;
-  int64_t row = m0 + 4 * r4;
-  if (row >= a.M) row = m0;                          // padding lanes re-read a valid row; never stored
-  const int64_t g0 = (int64_t)chunk * a.groups_per_chunk;
-  int64_t g1 = g0 + a.groups_per_chunk;
-  if (g1 > a.Cg) g1 = a.Cg;
-  const int64_t gfull = (a.C / kGroup < g1) ? a.C / kGroup : g1;   // groups with all 8 columns valid
-  const float* X = reinterpret_cast<const float*>(a.X);
-  const float* xp = X + b * a.batch_stride + row + (kGroup * g0 + h) * a.ld;
-  const int64_t ld2 = 2 * a.ld;
-  const f32x4* fp = reinterpret_cast<const f32x4*>(a.frag) + g0 * 64 + lane;
-  const int64_t fnt = a.Cg * 64;                     // f32x4 stride between N tiles
-
-  f32x16 acc[NT][4];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nt][v][i] = 0.f;
-
-  // Register ring of three stages (8 reduction columns = four 16-byte loads + one B fragment each).
-  // The loads of stage j+2 are issued one at a time BETWEEN the MFMAs of stage j: issuing them as a
-  // burst in front of the 16 MFMAs measured 18 % slower on MI355X (4.7 vs 5.6 TB/s, profiles/README.md),
-  // and without sched_barrier hipcc sinks them down to their first use.
-  f32x4 x0[4], x1[4], x2[4], f0[NT], f1[NT], f2[NT];
-  const int64_t ng = gfull > g0 ? gfull - g0 : 0;
-  const int64_t gstep = kGroup * a.ld;
-#define AO_LOAD_STAGE(XS, FS, GI)                                                                   \
-  {                                                                                                 \
-    const float* p_ = xp + (GI) * gstep;                                                            \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
-      XS[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p_ + s * ld2));             \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) FS[nt] = fp[(GI) * 64 + nt * fnt];            \
-  }
-#define AO_COMPUTE_STAGE(XS, FS)                                                                    \
-  {                                                                                                 \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                   \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                               \
-    _Pragma("unroll") for (int v = 0; v < 4; ++v)                                                   \
-        acc[nt][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(XS[s][v], FS[nt][s], acc[nt][v], 0, 0, 0); \
-  }
-  // consume stage (XC,FC) while fetching stage GI into (XL,FL)
-#define AO_MIX_STAGE(XC, FC, XL, FL, GI)                                                            \
-  {                                                                                                 \
-    const float* p_ = xp + (GI) * gstep;                                                            \
-    _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                             \
-        acc[nt][q & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(XC[q >> 2][q & 3], FC[nt][q >> 2], acc[nt][q & 3], 0, 0, 0); \
-      if ((q + 1) % SP == 0) {                                                                      \
-        const int li = (q + 1) / SP - 1;                                                            \
-        if (li < 4) XL[li] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p_ + li * ld2)); \
-        if (li == 4 || (SP == 4 && li == 3)) {                                                      \
-          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) FL[nt] = fp[(GI) * 64 + nt * fnt];      \
-        }                                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-      }                                                                                             \
-    }                                                                                               \
-  }
-  if (ng > 0) AO_LOAD_STAGE(x0, f0, 0)
-  if (ng > 1) AO_LOAD_STAGE(x1, f1, 1)
-  int64_t g = 0;
-  for (; g + 5 <= ng; g += 3) {                      // steady state: every prefetch is in range
-    AO_MIX_STAGE(x0, f0, x2, f2, g + 2)
-    AO_MIX_STAGE(x1, f1, x0, f0, g + 3)
-    AO_MIX_STAGE(x2, f2, x1, f1, g + 4)
-  }
-  for (; g + 3 <= ng; g += 3) {                      // at most one drained round
-    if (g + 2 < ng) AO_LOAD_STAGE(x2, f2, g + 2)
-    AO_COMPUTE_STAGE(x0, f0)
-    if (g + 3 < ng) AO_LOAD_STAGE(x0, f0, g + 3)
-    AO_COMPUTE_STAGE(x1, f1)
-    if (g + 4 < ng) AO_LOAD_STAGE(x1, f1, g + 4)
-    AO_COMPUTE_STAGE(x2, f2)
-  }
-  if (g < ng) AO_COMPUTE_STAGE(x0, f0)
-  if (g + 1 < ng) AO_COMPUTE_STAGE(x1, f1)
-  g = gfull > g0 ? gfull : g0;
-  // ragged tail group: columns >= C are clamped (finite data) and meet zero B fragments
-  if (g < g1) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      int64_t c = kGroup * g + 2 * s + h;
-      if (c >= a.C) c = a.C - 1;
-      const float* p = X + b * a.batch_stride + row + c * a.ld;
-      x0[s] = *reinterpret_cast<const f32x4*>(p);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) f0[nt] = (reinterpret_cast<const f32x4*>(a.frag) + g * 64 + lane)[nt * fnt];
-    AO_COMPUTE_STAGE(x0, f0)
-  }
-#undef AO_LOAD_STAGE
-#undef AO_COMPUTE_STAGE
-#undef AO_MIX_STAGE
-  // epilogue: C/D map col = lane&31, row rho = (reg&3) + 8*(reg>>2) + 4*(lane>>5); tile row = 4*rho+v
-  float* Tc = reinterpret_cast<float*>(a.T) + ((int64_t)chunk * a.trows + b * a.M) * a.R;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int r = 32 * nt + r4;
-    if (r < a.R) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int rho = (i & 3) + 8 * (i >> 2) + 4 * h;
-          const int64_t m = m0 + 4 * rho + v;
-          if (m < a.M) Tc[m * a.R + r] = acc[nt][v][i];
-        }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------
 // f32 contraction, 16-column tiles: v_mfma_f32_16x16x4_f32 for the first 16*NT columns of the factor and,
@@ -412,36 +276,18 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract16_f32(KArgs a) 
 // ---------------------------------------------------------------------------
 // f32 contraction of the LEADING (contiguous) mode:  T(m, r) = sum_i X[i + ld*m] * F(i, r)
 // ---------------------------------------------------------------------------
-// Here the reduction index is the contiguous one, so MFMA A operands (one unfolding row per lane)
-// cannot be loaded straight from HBM: a workgroup streams a [128 rows m] x [64 i] tile (128 segments
-// of 256 contiguous bytes) through registers into LDS (row stride 68 floats: ds_read_b128 of 16 rows at
-// one column offset hits 16 distinct 16-byte slots).  The four waves split the REDUCTION, not the rows:
-// wave w multiplies all 128 rows by i in [16w, 16w+16) of every chunk (ds_read_b128 = 4 consecutive i per
-// lane = 4 k-steps of v_mfma_f32_32x32x2_f32), so one B fragment serves four row tiles and B traffic is a
-// quarter of the tensor traffic (with rows split over waves it equalled it and the kernel ran 25 %
-// slower).  The four partial 128 x 32 tiles are summed through LDS at the end and written as one
-// contiguous block of T.  Loads of chunks c+2 / c+3 are in flight while chunk c is consumed; one barrier per
-// chunk (double-buffered LDS).
-// B fragments are packed so that lane (h, col) finds F[8g + 4h + t][col] for t = 0..3 in one float4.
+// Used only when the mode-permuted second copy of the tensor (solver.h CpBlock::Xp) is unavailable.  The
+// reduction index is the contiguous one, so MFMA A operands (one unfolding row per lane) cannot be loaded
+// straight from HBM: a workgroup streams a [128 rows m] x [64 i] tile (128 segments of 256 contiguous bytes)
+// through registers into LDS (row stride 68 floats: ds_read_b128 of 16 rows at one column offset hits 16
+// distinct 16-byte slots).  The four waves split the REDUCTION, not the rows, so one B fragment serves all row
+// tiles (with rows split over waves B traffic equalled the tensor traffic and the kernel ran 25 % slower); B
+// fragments are fetched one chunk ahead (their L2 latency cannot hide behind 0.4 us of MFMA work per chunk);
+// the four partial tiles are summed through LDS and written as one contiguous block of T.  Loads of chunks
+// c+2 / c+3 are in flight while chunk c is consumed; one barrier per chunk (double-buffered LDS).
 static constexpr int kLeadRows = 128;   // unfolding rows per workgroup
 static constexpr int kLeadKC = 64;      // reduction elements per chunk
 static constexpr int kLeadStride = 68;  // LDS row stride in floats
-
-__global__ void pack_frag_lead_f32(const double* __restrict__ F, int64_t ldF, int64_t C, int R, int NT,
-                                   int64_t Cg, float* __restrict__ frag) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over nt*Cg*64*4
-  int64_t total = (int64_t)NT * Cg * 256;
-  if (idx >= total) return;
-  int t = idx & 3;
-  int lane = (idx >> 2) & 63;
-  int64_t g = (idx >> 8) % Cg;
-  int nt = (int)((idx >> 8) / Cg);
-  int64_t c = 8 * g + 4 * (lane >> 5) + t;
-  int r = 32 * nt + (lane & 31);
-  float v = 0.f;
-  if (c < C && r < R) v = (float)F[c + ldF * r];
-  frag[idx] = v;
-}
 
 struct LArgs {
   const float* X;
@@ -451,142 +297,6 @@ struct LArgs {
   int chunks_per_slice;      // 64-element chunks per accumulation slice (blockIdx.y)
   int R;
 };
-
-template <int NT>
-__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void contract_lead_f32(LArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][kLeadRows][kLeadStride]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * kLeadRows;
-  const int slice = blockIdx.y;
-  const int64_t nchunks_total = (a.C + kLeadKC - 1) / kLeadKC;
-  const int64_t c0 = (int64_t)slice * a.chunks_per_slice;
-  int64_t c1 = c0 + a.chunks_per_slice;
-  if (c1 > nchunks_total) c1 = nchunks_total;
-  // staging map: 8 x 16-byte loads per thread, thread -> (row = (tid>>4) + 16q, 4 floats at 4*(tid&15))
-  const int srow = tid >> 4, scol = 4 * (tid & 15);
-  const float* rowp[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    int64_t m = m0 + srow + 16 * q;
-    if (m >= a.M) m = a.M - 1;                       // tail tile: re-read a valid row, never stored
-    rowp[q] = a.X + m * a.ld;
-  }
-  const int64_t last4 = a.ld - 4;                    // last 16-byte aligned group inside a row
-  f32x16 acc[NT][4];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int tl = 0; tl < 4; ++tl)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nt][tl][i] = 0.f;
-  const int r32 = lane & 31, h = lane >> 5;
-  const f32x4* fbase = reinterpret_cast<const f32x4*>(a.frag) + lane;
-  const int64_t fnt = a.Cg * 64;
-  // two register sets: while chunk k is consumed from LDS, chunk k+1 sits in one set (written to the
-  // other LDS buffer first) and chunks k+2 / k+3 are in flight -- one 16-byte load issued per 4 MFMAs
-  f32x4 sA[8], sB[8];
-#define AO_LEAD_LOAD1(ST, CH, Q)                                                                     \
-  {                                                                                                  \
-    int64_t i_ = (CH) * kLeadKC + scol;                                                              \
-    if (i_ > last4) i_ = last4;                                                                      \
-    ST[Q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rowp[Q] + i_));                \
-  }
-#define AO_LEAD_LOAD(ST, CH) { _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) AO_LEAD_LOAD1(ST, CH, q_) }
-#define AO_LEAD_WRITE(ST, BUF)                                                                       \
-  {                                                                                                  \
-    float* base_ = lds + (BUF) * (kLeadRows * kLeadStride);                                          \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                 \
-      *reinterpret_cast<f32x4*>(base_ + (srow + 16 * q_) * kLeadStride + scol) = ST[q_];             \
-  }
-  // B fragments of this wave's two 8-i groups, fetched one chunk ahead (their L2 latency would otherwise
-  // stall the wave at the head of every chunk: 32 MFMAs = 0.85 us of work per chunk cannot hide it)
-  f32x4 fA[NT][2], fB[NT][2];
-#define AO_LEAD_FRAG(FV, CH)                                                                         \
-  {                                                                                                  \
-    _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2) {                                               \
-      int64_t gg = (CH) * (kLeadKC / 8) + 2 * w + g2;                                                \
-      if (gg >= a.Cg) gg = a.Cg - 1;                                   /* ragged last chunk: masked in COMPUTE */ \
-      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) FV[nt][g2] = fbase[nt * fnt + gg * 64];      \
-    }                                                                                                \
-  }
-  // consume this wave's 16 i of chunk CH (B fragments FV) from LDS buffer BUF; meanwhile fetch the next
-  // chunk's fragments into FVN (if NF) and refill register set ST with chunk CHN (if PF)
-#define AO_LEAD_COMPUTE(BUF, CH, FV, FVN, NF, ST, CHN, PF)                                           \
-  {                                                                                                  \
-    const float* xs_ = lds + (BUF) * (kLeadRows * kLeadStride) + r32 * kLeadStride + 16 * w + 4 * h; \
-    if (NF) AO_LEAD_FRAG(FVN, (CH) + 1)                                                              \
-    _Pragma("unroll") for (int g2 = 0; g2 < 2; ++g2) {                                               \
-      f32x4 xv_[4];                                                                                  \
-      const bool live_ = (CH) * (kLeadKC / 8) + 2 * w + g2 < a.Cg;                                   \
-      _Pragma("unroll") for (int tl = 0; tl < 4; ++tl)                                               \
-        xv_[tl] = *reinterpret_cast<const f32x4*>(xs_ + 32 * tl * kLeadStride + 8 * g2);            \
-      __builtin_amdgcn_sched_barrier(0);                                                             \
-      _Pragma("unroll") for (int tl = 0; tl < 4; ++tl) {                                             \
-        if (live_) {                                                                                 \
-          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                          \
-            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                            \
-              acc[nt][tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv_[tl][t], FV[nt][g2][t], acc[nt][tl], 0, 0, 0); \
-        }                                                                                            \
-        if (PF) AO_LEAD_LOAD1(ST, CHN, 4 * g2 + tl)                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-      }                                                                                              \
-    }                                                                                                \
-  }
-  const int64_t n = c1 > c0 ? c1 - c0 : 0;
-  if (n > 0) {
-    AO_LEAD_LOAD(sA, c0)
-    AO_LEAD_FRAG(fA, c0)
-    AO_LEAD_WRITE(sA, 0)
-  }
-  if (n > 1) AO_LEAD_LOAD(sA, c0 + 1)
-  if (n > 2) AO_LEAD_LOAD(sB, c0 + 2)
-  __syncthreads();
-  for (int64_t k = 0; k < n; k += 2) {
-    if (k + 1 < n) AO_LEAD_WRITE(sA, 1)
-    if (k + 3 < n) AO_LEAD_COMPUTE(0, c0 + k, fA, fB, true, sA, c0 + k + 3, true)
-    else if (k + 1 < n) AO_LEAD_COMPUTE(0, c0 + k, fA, fB, true, sA, c0, false)
-    else AO_LEAD_COMPUTE(0, c0 + k, fA, fB, false, sA, c0, false)
-    __syncthreads();
-    if (k + 1 >= n) break;
-    if (k + 2 < n) AO_LEAD_WRITE(sB, 0)
-    if (k + 4 < n) AO_LEAD_COMPUTE(1, c0 + k + 1, fB, fA, true, sB, c0 + k + 4, true)
-    else if (k + 2 < n) AO_LEAD_COMPUTE(1, c0 + k + 1, fB, fA, true, sB, c0, false)
-    else AO_LEAD_COMPUTE(1, c0 + k + 1, fB, fA, false, sB, c0, false)
-    __syncthreads();
-  }
-#undef AO_LEAD_FRAG
-#undef AO_LEAD_LOAD1
-#undef AO_LEAD_LOAD
-#undef AO_LEAD_WRITE
-#undef AO_LEAD_COMPUTE
-  // sum the four waves' partial tiles through LDS (region w: [128 rows][33], column-padded), then write
-  // the 128 x R block of T, which is contiguous in memory, with flat coalesced stores
-  __syncthreads();
-  constexpr int kEpiStride = 33;
-  float* Tc = a.T + (int64_t)slice * a.M * a.R + m0 * a.R;
-  const int64_t rows_here = (a.M - m0 < kLeadRows) ? (a.M - m0) : kLeadRows;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    float* reg = lds + w * (kLeadRows * kEpiStride);
-#pragma unroll
-    for (int tl = 0; tl < 4; ++tl)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int rho = (i & 3) + 8 * (i >> 2) + 4 * h;
-        reg[(32 * tl + rho) * kEpiStride + r32] = acc[nt][tl][i];
-      }
-    __syncthreads();
-    const int ncol = (a.R - 32 * nt < 32) ? (a.R - 32 * nt) : 32;      // columns of this N tile
-    const int total = (int)rows_here * ncol;
-    for (int e = tid; e < total; e += 256) {
-      const int row = e / ncol, col = e - row * ncol;
-      const float* p = lds + row * kEpiStride + col;
-      const float v = (p[0] + p[kLeadRows * kEpiStride]) + (p[2 * kLeadRows * kEpiStride] + p[3 * kLeadRows * kEpiStride]);
-      Tc[(int64_t)row * a.R + 32 * nt + col] = v;
-    }
-    __syncthreads();
-  }
-}
 
 // ---------------------------------------------------------------------------
 // Leading-mode contraction with 16-column tiles (same idea as contract16_f32): wave w multiplies all 128
@@ -877,7 +587,6 @@ ContractPlan make_lead_plan(int64_t M, int64_t ld, int64_t C, int R) {
 static void launch_contract_lead(const void* X, const ContractPlan& pl, const double* F, int64_t ldF, void* frag_ws,
                                  void* T, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   const int64_t Cg = cdiv(pl.C, kGroup);
-  const int NT = nt_of(pl.R, AOADMM_PREC_F32);
   AO_REQUIRE(pl.ld % 4 == 0 && pl.ld >= 4, "f32 layout must be padded to 4");
   LArgs a;
   a.X = (const float*)X; a.frag = (const float*)frag_ws; a.T = (float*)T;
@@ -887,42 +596,23 @@ static void launch_contract_lead(const void* X, const ContractPlan& pl, const do
   AO_REQUIRE(nblk < (int64_t)2147483647, "tensor too large for one launch");
   dim3 grid((unsigned)nblk, (unsigned)pl.nchunk);
   const size_t sh = (size_t)2 * kLeadRows * kLeadStride * sizeof(float);
-  static const bool use32 = getenv("AOADMM_CONTRACT_32") != nullptr;     // development switch: 32x32x2 kernels
-  if (!use32) {
-    const int nt16 = (pl.R + 15) / 16;
-    const int64_t Cg16 = cdiv(pl.C, 16) + 1;           // + one all-zero group: the ragged last chunk multiplies by it
-    const int64_t total = (int64_t)nt16 * Cg16 * 256;
-    pack_frag_lead16_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, nt16, Cg16, (float*)frag_ws);
-    AO_KERNEL_CHECK();
-    static bool attr16 = false;
-    if (!attr16) {
-#define AO_SET(K) AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-      AO_SET(contract_lead16_f32<1>) AO_SET(contract_lead16_f32<2>) AO_SET(contract_lead16_f32<3>) AO_SET(contract_lead16_f32<4>)
-#undef AO_SET
-      attr16 = true;
-    }
-    if (ev0) AO_HIP(hipEventRecord(ev0, s));
-    if (nt16 == 1) contract_lead16_f32<1><<<grid, 256, sh, s>>>(a);
-    else if (nt16 == 2) contract_lead16_f32<2><<<grid, 256, sh, s>>>(a);
-    else if (nt16 == 3) contract_lead16_f32<3><<<grid, 256, sh, s>>>(a);
-    else if (nt16 == 4) contract_lead16_f32<4><<<grid, 256, sh, s>>>(a);
-    else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
-    if (ev1) AO_HIP(hipEventRecord(ev1, s));
-    AO_KERNEL_CHECK();
-    return;
-  }
-  const int64_t total = (int64_t)NT * Cg * 256;
-  pack_frag_lead_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (float*)frag_ws);
+  const int nt16 = (pl.R + 15) / 16;
+  const int64_t Cg16 = cdiv(pl.C, 16) + 1;           // + one all-zero group: the ragged last chunk multiplies by it
+  const int64_t total = (int64_t)nt16 * Cg16 * 256;
+  pack_frag_lead16_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, nt16, Cg16, (float*)frag_ws);
   AO_KERNEL_CHECK();
-  static bool attr = false;
-  if (!attr) {
-    AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_lead_f32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(contract_lead_f32<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    attr = true;
+  static bool attr16 = false;
+  if (!attr16) {
+#define AO_SET(K) AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    AO_SET(contract_lead16_f32<1>) AO_SET(contract_lead16_f32<2>) AO_SET(contract_lead16_f32<3>) AO_SET(contract_lead16_f32<4>)
+#undef AO_SET
+    attr16 = true;
   }
   if (ev0) AO_HIP(hipEventRecord(ev0, s));
-  if (NT == 1) contract_lead_f32<1><<<grid, 256, sh, s>>>(a);
-  else if (NT == 2) contract_lead_f32<2><<<grid, 256, sh, s>>>(a);
+  if (nt16 == 1) contract_lead16_f32<1><<<grid, 256, sh, s>>>(a);
+  else if (nt16 == 2) contract_lead16_f32<2><<<grid, 256, sh, s>>>(a);
+  else if (nt16 == 3) contract_lead16_f32<3><<<grid, 256, sh, s>>>(a);
+  else if (nt16 == 4) contract_lead16_f32<4><<<grid, 256, sh, s>>>(a);
   else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
   if (ev1) AO_HIP(hipEventRecord(ev1, s));
   AO_KERNEL_CHECK();
@@ -952,36 +642,22 @@ void launch_contract(const void* X, int prec, const ContractPlan& pl, const doub
   AO_REQUIRE(cdiv(a.ntiles, 4) < (int64_t)2147483647, "tensor too large for one launch");
   if (prec == AOADMM_PREC_F32) {
     AO_REQUIRE(pl.ld % 4 == 0 && pl.M % 4 == 0 && pl.batch_stride % 4 == 0, "f32 layout must be padded to 4");
-    static const bool use32 = getenv("AOADMM_CONTRACT_32") != nullptr;   // development switch: 32x32x2 kernel
-    if (!use32) {
-      // 16-column tiles; 1..4 leftover columns go to the vector pipe
-      const int rem = pl.R % 16;
-      const bool ex = pl.R > 16 && rem >= 1 && rem <= 4;
-      const int nt16 = ex ? pl.R / 16 : (pl.R + 15) / 16;
-      const int64_t total = (int64_t)nt16 * Cg * 128 + (ex ? Cg * 32 : 0);
-      pack_frag16_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, nt16, ex ? 1 : 0, Cg, (float*)frag_ws);
-      AO_KERNEL_CHECK();
-      if (ev0) AO_HIP(hipEventRecord(ev0, s));
-      if (nt16 == 1 && !ex) contract16_f32<1, false><<<grid, 256, 0, s>>>(a);
-      else if (nt16 == 1) contract16_f32<1, true><<<grid, 256, 0, s>>>(a);
-      else if (nt16 == 2 && !ex) contract16_f32<2, false><<<grid, 256, 0, s>>>(a);
-      else if (nt16 == 2) contract16_f32<2, true><<<grid, 256, 0, s>>>(a);
-      else if (nt16 == 3 && !ex) contract16_f32<3, false><<<grid, 256, 0, s>>>(a);
-      else if (nt16 == 3) contract16_f32<3, true><<<grid, 256, 0, s>>>(a);
-      else if (nt16 == 4) contract16_f32<4, false><<<grid, 256, 0, s>>>(a);
-      else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
-    } else {
-    int64_t total = (int64_t)NT * Cg * 256;
-    pack_frag_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (float*)frag_ws);
+    // 16-column tiles; 1..4 leftover columns go to the vector pipe
+    const int rem = pl.R % 16;
+    const bool ex = pl.R > 16 && rem >= 1 && rem <= 4;
+    const int nt16 = ex ? pl.R / 16 : (pl.R + 15) / 16;
+    const int64_t total = (int64_t)nt16 * Cg * 128 + (ex ? Cg * 32 : 0);
+    pack_frag16_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, nt16, ex ? 1 : 0, Cg, (float*)frag_ws);
     AO_KERNEL_CHECK();
     if (ev0) AO_HIP(hipEventRecord(ev0, s));
-    static const int sp = getenv("AOADMM_CONTRACT_SP") ? atoi(getenv("AOADMM_CONTRACT_SP")) : 4;
-    if (NT == 1 && sp == 3) contract_f32<1, 3><<<grid, 256, 0, s>>>(a);
-    else if (NT == 1 && sp == 2) contract_f32<1, 2><<<grid, 256, 0, s>>>(a);
-    else if (NT == 1) contract_f32<1, 4><<<grid, 256, 0, s>>>(a);
-    else if (NT == 2) contract_f32<2, 4><<<grid, 256, 0, s>>>(a);
+    if (nt16 == 1 && !ex) contract16_f32<1, false><<<grid, 256, 0, s>>>(a);
+    else if (nt16 == 1) contract16_f32<1, true><<<grid, 256, 0, s>>>(a);
+    else if (nt16 == 2 && !ex) contract16_f32<2, false><<<grid, 256, 0, s>>>(a);
+    else if (nt16 == 2) contract16_f32<2, true><<<grid, 256, 0, s>>>(a);
+    else if (nt16 == 3 && !ex) contract16_f32<3, false><<<grid, 256, 0, s>>>(a);
+    else if (nt16 == 3) contract16_f32<3, true><<<grid, 256, 0, s>>>(a);
+    else if (nt16 == 4) contract16_f32<4, false><<<grid, 256, 0, s>>>(a);
     else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
-    }
   } else {
     AO_REQUIRE(pl.ld % 2 == 0 && pl.M % 2 == 0 && pl.batch_stride % 2 == 0, "f64 layout must be padded to 2");
     int64_t total = (int64_t)NT * Cg * 128;

