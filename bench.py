@@ -109,6 +109,10 @@ def main():
     eng = pkg.Engine(local_rank)
     if world > 1:
         pkg.init_engine_comm(eng, dist)               # data plane: RCCL inside the library
+    elif os.environ.get('AOADMM_BENCH_ONE_RANK_COMM'):
+        # development switch: run the N > 1 data path (zero-filled own-rows buffer + ncclAllReduce of every MTTKRP
+        # output) with a one-rank RCCL communicator -- the only form a one-GPU box can exercise at full size
+        eng.comm_init_rank(eng.comm_unique_id(), 0, 1)
 
     I = J = K = args.size
     R = args.rank
