@@ -2,6 +2,7 @@
 // Reference: functions/cmtf_fun_AOADMM.m:591-623 (ADMM_constrained_only), :1420-1429
 // (update_constraint), :1079-1096 (eval_res_ADMM_constr); functions/constraints_to_prox.m.
 #include "admm.h"
+#include "device_utils.h"
 #include "hosteig.h"
 #include "loopctl.h"
 
@@ -1411,10 +1412,33 @@ __global__ void copy_add_k(double* V, double* Zold, const double* fac, const dou
     Zold[i] = Z[i];
   }
 }
-__global__ void dual_only_k(const double* fac, const double* Z, double* mu, int64_t n, const AdmmCtl* ctl) {
+// mu += fac - Z (:1063) and the four sums of eval_res_ADMM_constr in the same pass:
+// ||fac-Z||^2, ||fac||^2, ||mu||^2, ||Z-Zold||^2.  One block writes the slots itself; several blocks leave
+// per-block partial sums that dual_sums_fin_k adds in block order.
+__global__ __launch_bounds__(256) void dual_sums_k(const double* fac, const double* Z, double* mu, const double* Zold,
+                                                   int64_t n, double* slots, double* ws, const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    mu[i] = mu[i] + fac[i] - Z[i];
+  __shared__ double sh4[4];
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double f = fac[i], z = Z[i];
+    const double m = mu[i] + f - z;
+    mu[i] = m;
+    const double dz = z - Zold[i];
+    s0 += (f - z) * (f - z); s1 += f * f; s2 += m * m; s3 += dz * dz;
+  }
+  s0 = block256_sum(s0, sh4); s1 = block256_sum(s1, sh4); s2 = block256_sum(s2, sh4); s3 = block256_sum(s3, sh4);
+  if (threadIdx.x == 0) {
+    double* o = gridDim.x == 1 ? slots : ws + 4 * (int64_t)blockIdx.x;
+    o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+  }
+}
+__global__ void dual_sums_fin_k(double* slots, const double* ws, int nb, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  if (threadIdx.x >= 4) return;
+  double t = 0.0;
+  for (int b = 0; b < nb; ++b) t += ws[4 * b + threadIdx.x];
+  slots[threadIdx.x] = t;
 }
 
 void constraint_update(const ProxSpec& ps, const double* fac, double* Z, double* mu, double* Zold,
@@ -1427,12 +1451,14 @@ void constraint_update(const ProxSpec& ps, const double* fac, double* Z, double*
   copy_add_k<<<(unsigned)nb, 256, 0, s>>>(V, Zold, fac, Z, mu, n, ctl);
   AO_KERNEL_CHECK();
   prox_apply(ps, V, rows, Z, rows, rows, R, rho_dev, rho_mul, prox_ws, ctl, s, Zold, rows);   // Z = prox(fac+mu, rho)
-  dual_only_k<<<(unsigned)nb, 256, 0, s>>>(fac, Z, mu, n, ctl);                  // mu += fac - Z
+  int64_t nr = cdiv(n, 2048);
+  if (nr > 64) nr = 64;
+  dual_sums_k<<<(unsigned)nr, 256, 0, s>>>(fac, Z, mu, Zold, n, slots, red_ws, ctl);
   AO_KERNEL_CHECK();
-  sumsq_diff(slots + 0, fac, Z, n, red_ws, ctl, s);
-  sumsq_diff(slots + 1, fac, nullptr, n, red_ws, ctl, s);
-  sumsq_diff(slots + 2, mu, nullptr, n, red_ws, ctl, s);
-  sumsq_diff(slots + 3, Z, Zold, n, red_ws, ctl, s);
+  if (nr > 1) {
+    dual_sums_fin_k<<<1, 64, 0, s>>>(slots, red_ws, (int)nr, ctl);
+    AO_KERNEL_CHECK();
+  }
 }
 
 __global__ void admm_finalize_generic_k(FinalizeArgs fa, AdmmCtl* ctl) {

@@ -49,4 +49,14 @@ __device__ inline double block_sum_pow2(double v, double* sh) {
   return r;
 }
 
+// sum over a block of exactly 256 threads (four wavefronts); sh4 holds four doubles
+__device__ __forceinline__ double block256_sum(double v, double* sh4) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double r = sh4[0] + sh4[1] + sh4[2] + sh4[3];
+  __syncthreads();
+  return r;
+}
+
 }  // namespace aoadmm

@@ -46,27 +46,54 @@ void par2_gram(const double* B, const P2Dims& d, double* GB, hipStream_t s) {
   AO_KERNEL_CHECK();
 }
 
-// A{m} = sum_k X_k B_k diag(C(k,:)) ; C{m} = sum_k diag(C(k,:)) (B_k'B_k) diag(C(k,:))   (:163-164), k in order
-__global__ void par2_modeA_combine_k(const double* T1, const double* Cfac, const double* GB, P2Dims d, double* Amt,
-                                     double* Csys) {
-  const int nA = d.I * d.R, nC = d.R * d.R;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nA + nC; e += gridDim.x * blockDim.x) {
-    double acc = 0.0;
-    if (e < nA) {
-      const int r = e / d.I;
-      for (int k = 0; k < d.K; ++k) acc += T1[(int64_t)k * nA + e] * Cfac[k + d.K * r];
-      Amt[e] = acc;
-    } else {
-      const int f = e - nA, r = f % d.R, q = f / d.R;
-      for (int k = 0; k < d.K; ++k) acc += Cfac[k + d.K * r] * GB[(int64_t)k * nC + f] * Cfac[k + d.K * q];
-      Csys[f] = acc;
-    }
+// Sum over the K slabs of f(k) for a tile of `ew` consecutive outputs: 256 threads = ew outputs x ng = 256/ew slab
+// groups.  Every group adds its slabs in order, then the groups are folded by a fixed pairwise tree, so the result
+// does not depend on scheduling.  The value is returned in the threads of group 0.
+constexpr int kKsumThreads = 256;
+template <class F>
+__device__ inline double ksum_tile(bool live, int g, int ng, int ew, int K, double* red, F f) {
+  double acc = 0.0;
+  if (live)
+    for (int k = g; k < K; k += ng) acc += f(k);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = ng >> 1; s > 0; s >>= 1) {
+    if (g < s) red[threadIdx.x] += red[threadIdx.x + s * ew];
+    __syncthreads();
+  }
+  return red[threadIdx.x];
+}
+static inline int ksum_tile_width(int64_t n) { return n >= 16384 ? 64 : (n >= 2048 ? 16 : 4); }
+
+// A{m} = sum_k X_k B_k diag(C(k,:)) ; C{m} = sum_k diag(C(k,:)) (B_k'B_k) diag(C(k,:))   (:163-164)
+__global__ __launch_bounds__(kKsumThreads) void par2_modeA_combine_k(const double* T1, const double* Cfac,
+                                                                      const double* GB, P2Dims d, double* Amt,
+                                                                      double* Csys, int ew) {
+  __shared__ double red[kKsumThreads];
+  const int nA = d.I * d.R, nC = d.R * d.R, K = d.K;
+  const int ng = kKsumThreads / ew, ex = threadIdx.x % ew, g = threadIdx.x / ew;
+  const int e = blockIdx.x * ew + ex;
+  double v;
+  if (blockIdx.x * ew < nA) {            // tiles never straddle nA: the host rounds nA up to a tile boundary
+    const bool lv = e < nA;
+    const int r = lv ? e / d.I : 0;
+    v = ksum_tile(lv, g, ng, ew, K, red, [&](int k) { return T1[(int64_t)k * nA + e] * Cfac[k + K * r]; });
+    if (lv && g == 0) Amt[e] = v;
+  } else {
+    const int f = e - (int)((nA + ew - 1) / ew) * ew;
+    const bool lv = f < nC;
+    const int r = lv ? f % d.R : 0, q = lv ? f / d.R : 0;
+    v = ksum_tile(lv, g, ng, ew, K, red,
+                  [&](int k) { return Cfac[k + K * r] * GB[(int64_t)k * nC + f] * Cfac[k + K * q]; });
+    if (lv && g == 0) Csys[f] = v;
   }
 }
 void par2_modeA_combine(const double* T1, const double* Cfac, const double* GB, const P2Dims& d, double* Amt,
                         double* Csys, hipStream_t s) {
-  const int n = d.I * d.R + d.R * d.R;
-  par2_modeA_combine_k<<<(n + 127) / 128, 128, 0, s>>>(T1, Cfac, GB, d, Amt, Csys);
+  const int64_t nA = (int64_t)d.I * d.R, nC = (int64_t)d.R * d.R;
+  const int ew = ksum_tile_width(nA + nC);
+  const unsigned nb = (unsigned)(cdiv(nA, ew) + cdiv(nC, ew));
+  par2_modeA_combine_k<<<nb, kKsumThreads, 0, s>>>(T1, Cfac, GB, d, Amt, Csys, ew);
   AO_KERNEL_CHECK();
 }
 
@@ -176,71 +203,68 @@ __global__ void par2_b_primal_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
 }
 
 // P_k = U*V' of svd(W_k,'econ') (:532-534) by one-sided (Hestenes) Jacobi: W*Jrot has orthogonal
-// columns, U = W*Jrot/sigma, V = Jrot.
-__global__ __launch_bounds__(kP2Threads) void par2_polar_k(double* W, double* P, P2Dims d, const AdmmCtl* ctl) {
+// columns, U = W*Jrot/sigma, V = Jrot.  One wave per slab: the three column products of a pair are reduced by a
+// butterfly over the 64 lanes, which leaves bit-identical sums in every lane, so each lane derives the rotation
+// itself and nothing is exchanged through memory.  W_k is staged in LDS when it fits (in_lds), else rotated in place.
+static_assert(kP2Threads == 64, "par2_polar_k reduces over exactly one wavefront");
+__device__ inline double wave_sum64(double v) {
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__global__ __launch_bounds__(kP2Threads) void par2_polar_k(double* W, double* P, P2Dims d, const AdmmCtl* ctl,
+                                                            int in_lds) {
   CTL_GUARD(ctl);
-  extern __shared__ double Jr[];          // R*R
-  __shared__ double sh[kP2Threads];
-  __shared__ double cs[2];
-  __shared__ int rotated;
-  const int k = blockIdx.x, R = d.R;
+  extern __shared__ double Jr[];          // R*R, then W_k (n*R) when in_lds
+  const int k = blockIdx.x, R = d.R, lane = threadIdx.x;
   const int64_t o = d.off[k];
   const int n = (int)(d.off[k + 1] - o);
-  double* Wk = W + o * R;
   double* Pk = P + o * R;
-  for (int e = threadIdx.x; e < R * R; e += blockDim.x) Jr[e] = (e % R == e / R) ? 1.0 : 0.0;
+  double* Wk = W + o * R;
+  if (in_lds) {
+    double* Wl = Jr + R * R;
+    for (int e = lane; e < n * R; e += 64) Wl[e] = Wk[e];
+    Wk = Wl;
+  }
+  for (int e = lane; e < R * R; e += 64) Jr[e] = (e % R == e / R) ? 1.0 : 0.0;
   __syncthreads();
   for (int sweep = 0; sweep < 60; ++sweep) {
-    if (threadIdx.x == 0) rotated = 0;
-    __syncthreads();
+    bool rotated = false;
     for (int p = 0; p < R - 1; ++p)
       for (int q = p + 1; q < R; ++q) {
         double* wp = Wk + n * p;
         double* wq = Wk + n * q;
         double al = 0, be = 0, ga = 0;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) { al += wp[i] * wp[i]; be += wq[i] * wq[i]; ga += wp[i] * wq[i]; }
-        al = block_sum_pow2(al, sh); be = block_sum_pow2(be, sh); ga = block_sum_pow2(ga, sh);
-        if (threadIdx.x == 0) {
-          double c = 1.0, s = 0.0;
-          if (ga != 0.0 && fabs(ga) > 1e-15 * sqrt(al * be)) {
-            const double zeta = (be - al) / (2.0 * ga);
-            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            c = 1.0 / sqrt(1.0 + t * t);
-            s = c * t;
-            rotated = 1;
-          }
-          cs[0] = c; cs[1] = s;
-        }
-        __syncthreads();
-        const double c = cs[0], s = cs[1];
-        if (s != 0.0) {
-          for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        for (int i = lane; i < n; i += 64) { al += wp[i] * wp[i]; be += wq[i] * wq[i]; ga += wp[i] * wq[i]; }
+        al = wave_sum64(al); be = wave_sum64(be); ga = wave_sum64(ga);
+        if (ga != 0.0 && fabs(ga) > 1e-15 * sqrt(al * be)) {           // uniform over the wave
+          const double zeta = (be - al) / (2.0 * ga);
+          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double c = 1.0 / sqrt(1.0 + t * t);
+          const double sn = c * t;
+          rotated = true;
+          for (int i = lane; i < n; i += 64) {
             const double x = wp[i], y = wq[i];
-            wp[i] = c * x - s * y;
-            wq[i] = s * x + c * y;
+            wp[i] = c * x - sn * y;
+            wq[i] = sn * x + c * y;
           }
-          for (int i = threadIdx.x; i < R; i += blockDim.x) {
+          for (int i = lane; i < R; i += 64) {
             const double x = Jr[i + R * p], y = Jr[i + R * q];
-            Jr[i + R * p] = c * x - s * y;
-            Jr[i + R * q] = s * x + c * y;
+            Jr[i + R * p] = c * x - sn * y;
+            Jr[i + R * q] = sn * x + c * y;
           }
         }
-        __syncthreads();
       }
-    const int any = rotated;
-    __syncthreads();
-    if (!any) break;
+    if (!rotated) break;
   }
   for (int p = 0; p < R; ++p) {
     double* wp = Wk + n * p;
     double al = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) al += wp[i] * wp[i];
-    al = block_sum_pow2(al, sh);
-    const double sg = sqrt(al);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) wp[i] = sg > 0 ? wp[i] / sg : 0.0;
-    __syncthreads();
+    for (int i = lane; i < n; i += 64) al += wp[i] * wp[i];
+    const double sg = sqrt(wave_sum64(al));
+    for (int i = lane; i < n; i += 64) wp[i] = sg > 0 ? wp[i] / sg : 0.0;
   }
-  for (int e = threadIdx.x; e < n * R; e += blockDim.x) {
+  __syncthreads();
+  for (int e = lane; e < n * R; e += 64) {
     const int i = e % n, r = e / n;
     double acc = 0.0;
     for (int q = 0; q < R; ++q) acc += Wk[i + n * q] * Jr[r + R * q];
@@ -262,15 +286,20 @@ __global__ void par2_deltab_part_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
     a.part[(int64_t)k * R * R + e] = a.rho[k] * acc;
   }
 }
-// DeltaB_old = DeltaB ; DeltaB = sum_k part[k] / sum_k rho_k   (:537-544), k in order
-__global__ void par2_deltab_combine_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
+// DeltaB_old = DeltaB ; DeltaB = sum_k part[k] / sum_k rho_k   (:537-544)
+__global__ __launch_bounds__(kKsumThreads) void par2_deltab_combine_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl, int ew) {
   CTL_GUARD(ctl);
-  const int R = d.R;
+  __shared__ double red[kKsumThreads];
+  __shared__ double red2[kKsumThreads];
+  const int R = d.R, K = d.K;
   double sr = 0.0;
-  for (int k = 0; k < d.K; ++k) sr += a.rho[k];
-  for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
-    double acc = 0.0;
-    for (int k = 0; k < d.K; ++k) acc += a.part[(int64_t)k * R * R + e];
+  for (int k = threadIdx.x; k < K; k += kKsumThreads) sr += a.rho[k];
+  sr = block_sum_pow2(sr, red2);
+  const int ng = kKsumThreads / ew, ex = threadIdx.x % ew, g = threadIdx.x / ew;
+  const int e = blockIdx.x * ew + ex;
+  const bool lv = e < R * R;
+  const double acc = ksum_tile(lv, g, ng, ew, K, red, [&](int k) { return a.part[(int64_t)k * R * R + e]; });
+  if (lv && g == 0) {
     a.DeltaBold[e] = a.DeltaB[e];
     a.DeltaB[e] = acc / sr;
   }
@@ -312,11 +341,14 @@ void par2_b_iteration(const P2BArgs& a, const P2Dims& d, const AdmmCtl* ctl, hip
   const size_t rr = (size_t)d.R * d.R * sizeof(double);
   par2_b_primal_k<<<d.K, kP2Threads, 2 * rr, s>>>(a, d, ctl);
   AO_KERNEL_CHECK();
-  par2_polar_k<<<d.K, kP2Threads, rr, s>>>(a.W, a.P, d, ctl);
+  const size_t wl = (size_t)d.Jmax * d.R * sizeof(double);
+  const int in_lds = rr + wl <= 48 * 1024;
+  par2_polar_k<<<d.K, kP2Threads, rr + (in_lds ? wl : 0), s>>>(a.W, a.P, d, ctl, in_lds);
   AO_KERNEL_CHECK();
   par2_deltab_part_k<<<d.K, kP2Threads, 0, s>>>(a, d, ctl);
   AO_KERNEL_CHECK();
-  par2_deltab_combine_k<<<1, 256, 0, s>>>(a, d, ctl);
+  const int ew = ksum_tile_width((int64_t)d.R * d.R);
+  par2_deltab_combine_k<<<(unsigned)cdiv((int64_t)d.R * d.R, ew), kKsumThreads, 0, s>>>(a, d, ctl, ew);
   AO_KERNEL_CHECK();
   par2_b_dual_k<<<d.K, kP2Threads, 2 * rr, s>>>(a, d, ctl);
   AO_KERNEL_CHECK();
@@ -414,11 +446,13 @@ void par2_b_constraint(const ProxSpec& ps, const double* B, double* Z, double* m
   AO_KERNEL_CHECK();
 }
 
-__global__ void par2_b_finalize_k(const double* norms, int K, int use_constr, AdmmCtl* ctl, int max_inner,
-                                  double tpc, double tpz, double tdc, double tdz) {
-  if (ctl->active == 0 || threadIdx.x != 0) return;
+__global__ __launch_bounds__(kKsumThreads) void par2_b_finalize_k(const double* norms, int K, int use_constr,
+                                                                   AdmmCtl* ctl, int max_inner, double tpc,
+                                                                   double tpz, double tdc, double tdz) {
+  if (ctl->active == 0) return;
+  __shared__ double red[kKsumThreads];
   double pc = 0, dc = 0, pz = 0, dz = 0;
-  for (int k = 0; k < K; ++k) {
+  for (int k = threadIdx.x; k < K; k += kKsumThreads) {
     const double* nk = norms + (int64_t)k * 8;
     const double nb = sqrt(nk[1]);
     pc += sqrt(nk[0]) / nb / K;                                 // :583
@@ -429,6 +463,9 @@ __global__ void par2_b_finalize_k(const double* norms, int K, int use_constr, Ad
       dz += (sc > 0 ? sqrt(nk[6]) / sc : sqrt(nk[6])) / K;       // :572-577
     }
   }
+  pc = block_sum_pow2(pc, red); dc = block_sum_pow2(dc, red);
+  pz = block_sum_pow2(pz, red); dz = block_sum_pow2(dz, red);
+  if (threadIdx.x != 0) return;
   ctl->res[0] = pc; ctl->res[1] = pz; ctl->res[2] = dc; ctl->res[3] = dz;
   const int it = ctl->iters + 1;
   ctl->iters = it;
@@ -436,7 +473,7 @@ __global__ void par2_b_finalize_k(const double* norms, int K, int use_constr, Ad
 }
 void par2_b_finalize(const double* norms, int K, int use_constr, AdmmCtl* ctl, int max_inner, double tol_pr_coupl,
                      double tol_pr_constr, double tol_du_coupl, double tol_du_constr, hipStream_t s) {
-  par2_b_finalize_k<<<1, 64, 0, s>>>(norms, K, use_constr, ctl, max_inner, tol_pr_coupl, tol_pr_constr, tol_du_coupl,
+  par2_b_finalize_k<<<1, kKsumThreads, 0, s>>>(norms, K, use_constr, ctl, max_inner, tol_pr_coupl, tol_pr_constr, tol_du_coupl,
                                      tol_du_constr);
   AO_KERNEL_CHECK();
 }

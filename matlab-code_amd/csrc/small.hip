@@ -174,14 +174,6 @@ void atb_small(double* out, const double* A, int64_t lda, const double* B, int64
 // ---------------------------------------------------------------------------
 // batch of independent reductions in one launch (the objective evaluation needs ~10 of them per outer
 // iteration; one kernel each was ~10 us of latency apiece).  grid = (nsplit, ntasks); fixed summation order.
-__device__ __forceinline__ double block256_sum(double v, double* sh4) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
-  __syncthreads();
-  const double r = sh4[0] + sh4[1] + sh4[2] + sh4[3];
-  __syncthreads();
-  return r;
-}
 __global__ __launch_bounds__(256) void reduce_batch_k(ReduceBatch rb, double* ws) {
   __shared__ double sh4[4];
   const ReduceTask& tk = rb.t[blockIdx.y];
