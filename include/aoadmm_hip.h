@@ -173,6 +173,9 @@ int aoadmm_model_end(aoadmm_ctx* ctx);
 int aoadmm_tensor_upload(aoadmm_ctx* ctx, int p, const double* data, int precision);
 int aoadmm_tensor_upload_rows(aoadmm_ctx* ctx, int p, const double* block, int64_t row_offset,
                               int64_t local_rows, int precision);
+/* PARAFAC2 slab k (I x J_k).  k = AOADMM_ALL_SLABS: the K slabs back to back (I x sum J_k) in one transfer;
+ * the same convention holds for aoadmm_par2_slab_mask_upload and for the cell-valued state fields below. */
+#define AOADMM_ALL_SLABS (-1)
 int aoadmm_par2_slab_upload(aoadmm_ctx* ctx, int p, int k, const double* Xk);
 /* Z.miss{p} (cmtf_AOADMM.m:68-121): one byte per entry, 1 = observed, 0 = missing, same shape and
  * column-major order as Z.object{p} (the FULL array also when row-sharded) / as slab k.  Upload after the
@@ -187,7 +190,8 @@ int aoadmm_tensor_synth(aoadmm_ctx* ctx, int p, int rank, uint64_t seed, double 
 int aoadmm_tensor_normsq(aoadmm_ctx* ctx, int p, double* out);
 
 /* ---- state (the struct G) ---------------------------------------------- */
-/* slab = k for cell-valued fields (PARAFAC2 B mode, P, mu_DeltaB), else 0 */
+/* slab = k for cell-valued fields (PARAFAC2 B mode, P, mu_DeltaB), else 0.  slab = AOADMM_ALL_SLABS moves
+ * all K cells at once: host holds them back to back, each J_k x R column-major, rows = sum J_k. */
 int aoadmm_state_set(aoadmm_ctx* ctx, int field, int index, int slab, const double* host,
                      int64_t rows, int64_t cols);
 int aoadmm_state_get(aoadmm_ctx* ctx, int field, int index, int slab, double* host, int64_t rows,

@@ -18,6 +18,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_NOT_PD, ERR_RCCL, ERR_UNSUPPORTED, ERR_NOMEM = ran
 PREC_F64, PREC_F32 = 0, 1
 (F_FAC, F_CONSTRAINT_FAC, F_CONSTRAINT_DUAL, F_COUPLING_FAC, F_COUPLING_DUAL, F_DELTAB, F_P,
  F_MU_DELTAB) = range(8)
+ALL_SLABS = -1            # AOADMM_ALL_SLABS
 
 # every symbol include/aoadmm_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [

@@ -586,8 +586,9 @@ struct StateLoc {
   int64_t rows, cols;
 };
 static StateLoc slab_loc(DevBuf& buf, const ModeInfo& mB, int slab) {
-  AO_REQUIRE(slab >= 0 && slab < mB.K, "slab %d out of range [0,%d)", slab, mB.K);
   buf.ensure((size_t)mB.rows * mB.R * sizeof(double));
+  if (slab == AOADMM_ALL_SLABS) return StateLoc{buf.d(), mB.rows, (int64_t)mB.R};   // all K slabs back to back
+  AO_REQUIRE(slab >= 0 && slab < mB.K, "slab %d out of range [0,%d)", slab, mB.K);
   return StateLoc{buf.d() + mB.off_k[slab] * mB.R, mB.rows_k[slab], (int64_t)mB.R};
 }
 
@@ -613,10 +614,10 @@ void Engine::state_set(int field, int index, int slab, const double* host, int64
       b.has_DeltaB = true;
     } else if (field == AOADMM_F_P) {
       loc = slab_loc(b.P, mB, slab);
-      b.have_P[slab] = 1;
+      if (slab == AOADMM_ALL_SLABS) b.have_P.assign(b.K, 1); else b.have_P[slab] = 1;
     } else {
       loc = slab_loc(b.muDB, mB, slab);
-      b.have_mu[slab] = 1;
+      if (slab == AOADMM_ALL_SLABS) b.have_mu.assign(b.K, 1); else b.have_mu[slab] = 1;
     }
   } else {
     check_mode(index);

@@ -58,11 +58,13 @@ void Engine::par2_slab_upload(int p, int k, const double* Xk) {
   AO_REQUIRE(Xk != nullptr, "null slab");
   AO_HIP(hipSetDevice(device_));
   Par2Block& b = tensors_[p].p2;
-  AO_REQUIRE(k >= 0 && k < b.K, "slab %d out of range", k);
-  const int64_t Jk = b.off_h[k + 1] - b.off_h[k];
-  AO_HIP(hipMemcpyAsync(b.X.d() + (int64_t)b.I * b.off_h[k], Xk, (size_t)b.I * Jk * sizeof(double), hipMemcpyHostToDevice, stream_));
+  AO_REQUIRE(k == AOADMM_ALL_SLABS || (k >= 0 && k < b.K), "slab %d out of range", k);
+  const bool all = k == AOADMM_ALL_SLABS;                  // I x sum(J_k): the slabs back to back
+  const int64_t o = all ? 0 : b.off_h[k];
+  const int64_t Jk = all ? b.Jtot : b.off_h[k + 1] - b.off_h[k];
+  AO_HIP(hipMemcpyAsync(b.X.d() + (int64_t)b.I * o, Xk, (size_t)b.I * Jk * sizeof(double), hipMemcpyHostToDevice, stream_));
   AO_HIP(hipStreamSynchronize(stream_));
-  b.have_slab[k] = 1;
+  if (all) b.have_slab.assign(b.K, 1); else b.have_slab[k] = 1;
   tensors_[p].blk.has_data = std::all_of(b.have_slab.begin(), b.have_slab.end(), [](char c) { return c != 0; });
   tensors_[p].normsq_valid = false;
 }
@@ -73,14 +75,15 @@ void Engine::par2_slab_mask_upload(int p, int k, const uint8_t* mask) {
   AO_REQUIRE(mask != nullptr, "null mask");
   AO_HIP(hipSetDevice(device_));
   Par2Block& b = tensors_[p].p2;
-  AO_REQUIRE(k >= 0 && k < b.K, "slab %d out of range", k);
+  AO_REQUIRE(k == AOADMM_ALL_SLABS || (k >= 0 && k < b.K), "slab %d out of range", k);
   if (!b.has_mask) {
     b.mask.alloc((size_t)b.I * b.Jtot);
     AO_HIP(hipMemsetAsync(b.mask.p, 1, (size_t)b.I * b.Jtot, stream_));     // slabs without a mask: fully observed
     b.has_mask = true;
   }
-  const int64_t Jk = b.off_h[k + 1] - b.off_h[k];
-  AO_HIP(hipMemcpyAsync(b.mask.as<uint8_t>() + (int64_t)b.I * b.off_h[k], mask, (size_t)b.I * Jk, hipMemcpyHostToDevice, stream_));
+  const int64_t o = k == AOADMM_ALL_SLABS ? 0 : b.off_h[k];
+  const int64_t Jk = k == AOADMM_ALL_SLABS ? b.Jtot : b.off_h[k + 1] - b.off_h[k];
+  AO_HIP(hipMemcpyAsync(b.mask.as<uint8_t>() + (int64_t)b.I * o, mask, (size_t)b.I * Jk, hipMemcpyHostToDevice, stream_));
   AO_HIP(hipStreamSynchronize(stream_));
   tensors_[p].normsq_valid = false;
 }

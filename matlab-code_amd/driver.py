@@ -313,9 +313,9 @@ def build_model(eng, Z, precision='f64'):
                 mk = np.asfortranarray(mk != 0, dtype=np.uint8)
                 capi.check(lib.aoadmm_tensor_mask_upload(eng.h, p, mk.ctypes.data_as(C.POINTER(C.c_uint8))))
         else:
-            for k, Xk in enumerate(Z['object'][p]):
-                Xk = capi.as_f(Xk)
-                capi.check(lib.aoadmm_par2_slab_upload(eng.h, p, k, capi.dptr(Xk)))
+            # the slabs back to back (each I x J_k, column-major) in one transfer
+            Xall = np.concatenate([np.asarray(Xk, dtype=np.float64).ravel(order='F') for Xk in Z['object'][p]])
+            capi.check(lib.aoadmm_par2_slab_upload(eng.h, p, capi.ALL_SLABS, capi.dptr(Xall)))
             if miss[p] is not None:                                                  # :98-120
                 K = len(Z['object'][p])
                 if not isinstance(miss[p], (list, tuple)) or len(miss[p]) != K:
@@ -328,6 +328,27 @@ def build_model(eng, Z, precision='f64'):
                         raise ValueError('Z.miss{%d}{%d} size does not match Z.object{%d}{%d}.' % (p + 1, k + 1, p + 1, k + 1))
                     mk = np.asfortranarray(mk != 0, dtype=np.uint8)
                     capi.check(lib.aoadmm_par2_slab_mask_upload(eng.h, p, k, mk.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+
+def _put_cells(eng, field, index, cells):
+    """A cell array of J_k x R matrices -> the device in one transfer (slab = AOADMM_ALL_SLABS)."""
+    cells = [np.asarray(c, dtype=np.float64) for c in cells]
+    cols = cells[0].shape[1]
+    packed = np.concatenate([c.ravel(order='F') for c in cells])
+    capi.check(eng.lib.aoadmm_state_set(eng.h, field, index, capi.ALL_SLABS, capi.dptr(packed),
+                                        sum(c.shape[0] for c in cells), cols))
+
+
+def _get_cells(eng, field, index, shapes):
+    rows = sum(s[0] for s in shapes)
+    cols = shapes[0][1]
+    packed = np.zeros(rows * cols)
+    capi.check(eng.lib.aoadmm_state_get(eng.h, field, index, capi.ALL_SLABS, capi.dptr(packed), rows, cols))
+    out, o = [], 0
+    for (r, c) in shapes:
+        out.append(np.array(packed[o:o + r * c].reshape((r, c), order='F'), order='F'))
+        o += r * c
+    return out
 
 
 def _put(eng, field, index, slab, a):
@@ -349,8 +370,7 @@ def upload_state(eng, Z, G):
     for m in range(nb_modes):
         F = G['fac'][m]
         if isinstance(F, (list, tuple)):
-            for k, Fk in enumerate(F):
-                _put(eng, capi.F_FAC, m, k, Fk)
+            _put_cells(eng, capi.F_FAC, m, F)
         else:
             _put(eng, capi.F_FAC, m, 0, F)
         for field, key in ((capi.F_CONSTRAINT_FAC, 'constraint_fac'), (capi.F_CONSTRAINT_DUAL, 'constraint_dual_fac'),
@@ -359,8 +379,7 @@ def upload_state(eng, Z, G):
             if v is None or (isinstance(v, (list, tuple)) and len(v) == 0):
                 continue
             if isinstance(v, (list, tuple)):
-                for k, vk in enumerate(v):
-                    _put(eng, field, m, k, vk)
+                _put_cells(eng, field, m, v)
             else:
                 _put(eng, field, m, 0, v)
     for n, D in enumerate(G.get('coupling_fac', [])):
@@ -368,10 +387,8 @@ def upload_state(eng, Z, G):
             _put(eng, capi.F_COUPLING_FAC, n, 0, D)
     for p, DB in G.get('DeltaB', {}).items():
         _put(eng, capi.F_DELTAB, p, 0, DB)
-        for k, Pk in enumerate(G['P'][p]):
-            _put(eng, capi.F_P, p, k, Pk)
-        for k, Mk in enumerate(G['mu_DeltaB'][p]):
-            _put(eng, capi.F_MU_DELTAB, p, k, Mk)
+        _put_cells(eng, capi.F_P, p, G['P'][p])
+        _put_cells(eng, capi.F_MU_DELTAB, p, G['mu_DeltaB'][p])
 
 
 def download_state(eng, Z, G):
@@ -381,7 +398,7 @@ def download_state(eng, Z, G):
 
     def pull(field, index, ref):
         if isinstance(ref, (list, tuple)):
-            return [_get(eng, field, index, k, np.shape(rk)) for k, rk in enumerate(ref)]
+            return _get_cells(eng, field, index, [np.shape(rk) for rk in ref])
         ref = np.asarray(ref)
         shp = ref.shape if ref.ndim == 2 else (ref.shape[0], 1)
         return _get(eng, field, index, 0, shp)

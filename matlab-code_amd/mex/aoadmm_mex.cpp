@@ -18,6 +18,7 @@
  * `cmtf:hip:unsupported`, which the wrapper catches to fall back to the original
  * MATLAB implementation.
  */
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -101,7 +102,18 @@ void put_state(int field_id, int index, int slab, const mxArray* a) {
 void put_state_maybe_cell(int field_id, int index, const mxArray* a) {
   if (!a || mxIsEmpty(a)) return;
   if (mxIsCell(a)) {
-    for (mwSize k = 0; k < mxGetNumberOfElements(a); ++k) put_state(field_id, index, (int)k, mxGetCell(a, k));
+    // all cells in one transfer: J_k x R blocks back to back (AOADMM_ALL_SLABS)
+    std::vector<double> packed;
+    int64_t rows = 0, cols = 0;
+    for (mwSize k = 0; k < mxGetNumberOfElements(a); ++k) {
+      const mxArray* ak = mxGetCell(a, k);
+      if (!ak || mxIsEmpty(ak)) mexErrMsgIdAndTxt("cmtf:hip:state", "empty cell %d in a cell-valued state field", (int)k + 1);
+      const double* d = mxGetDoubles(ak);
+      packed.insert(packed.end(), d, d + mxGetNumberOfElements(ak));
+      rows += (int64_t)mxGetM(ak);
+      cols = (int64_t)mxGetN(ak);
+    }
+    check(aoadmm_state_set(g_ctx, field_id, index, AOADMM_ALL_SLABS, packed.data(), rows, cols));
   } else {
     put_state(field_id, index, 0, a);
   }
@@ -111,10 +123,19 @@ mxArray* get_like(int field_id, int index, const mxArray* ref) {
   if (!ref || mxIsEmpty(ref)) return mxCreateDoubleMatrix(0, 0, mxREAL);
   if (mxIsCell(ref)) {
     mxArray* c = mxCreateCellMatrix(mxGetM(ref), mxGetN(ref));
+    int64_t rows = 0, cols = 0;
+    for (mwSize k = 0; k < mxGetNumberOfElements(ref); ++k) {
+      rows += (int64_t)mxGetM(mxGetCell(ref, k));
+      cols = (int64_t)mxGetN(mxGetCell(ref, k));
+    }
+    std::vector<double> packed((size_t)(rows * cols));
+    check(aoadmm_state_get(g_ctx, field_id, index, AOADMM_ALL_SLABS, packed.data(), rows, cols));
+    size_t o0 = 0;
     for (mwSize k = 0; k < mxGetNumberOfElements(ref); ++k) {
       const mxArray* rk = mxGetCell(ref, k);
       mxArray* o = mxCreateDoubleMatrix(mxGetM(rk), mxGetN(rk), mxREAL);
-      check(aoadmm_state_get(g_ctx, field_id, index, (int)k, mxGetDoubles(o), (int64_t)mxGetM(rk), (int64_t)mxGetN(rk)));
+      std::copy(packed.begin() + o0, packed.begin() + o0 + mxGetNumberOfElements(rk), mxGetDoubles(o));
+      o0 += mxGetNumberOfElements(rk);
       mxSetCell(c, k, o);
     }
     return c;
@@ -232,8 +253,12 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   for (int p = 0; p < P; ++p) {
     const mxArray* obj = mxGetCell(object, p);
     if (mxIsCell(obj)) {
-      for (mwSize k = 0; k < mxGetNumberOfElements(obj); ++k)
-        check(aoadmm_par2_slab_upload(g_ctx, p, (int)k, mxGetDoubles(mxGetCell(obj, k))));
+      std::vector<double> packed;                         // the slabs back to back, one transfer
+      for (mwSize k = 0; k < mxGetNumberOfElements(obj); ++k) {
+        const mxArray* xk = mxGetCell(obj, k);
+        packed.insert(packed.end(), mxGetDoubles(xk), mxGetDoubles(xk) + mxGetNumberOfElements(xk));
+      }
+      check(aoadmm_par2_slab_upload(g_ctx, p, AOADMM_ALL_SLABS, packed.data()));
     } else {
       check(aoadmm_tensor_upload(g_ctx, p, mxGetDoubles(dense_data(obj)), precision));
     }

@@ -150,3 +150,32 @@ def test_mttkrp_nway(pkg, eng, dims, prec, tol):
         ref = o_mttkrp(X, U, n)
         got = eng.mttkrp(X, U, n, precision=prec)
         assert rel_fro(got, ref) < tol, (n, rel_fro(got, ref))
+
+
+def test_cell_state_one_slab_at_a_time_equals_all_slabs(pkg, eng):
+    """Cell-valued fields of G (PARAFAC2 B_k): per-slab transfers and the AOADMM_ALL_SLABS form address the same memory."""
+    import ctypes as C
+    from helpers import script4_model
+    capi = __import__('importlib').import_module('matlab-code_amd._capi')
+    rng = np.random.default_rng(3)
+    Z, io = script4_model(rng, K=5)
+    Z['_ranks'] = [3, 3, 3]
+    pkg.build_model(eng, Z, 'f64')
+    R = 3
+    cells = [np.asfortranarray(rng.standard_normal((j, R))) for j in Z['size'][1]]
+    for k, c in enumerate(cells):                                        # slab by slab in ...
+        capi.check(eng.lib.aoadmm_state_set(eng.h, capi.F_FAC, 1, k, capi.dptr(c), c.shape[0], R))
+    rows = sum(c.shape[0] for c in cells)
+    packed = np.zeros(rows * R)                                          # ... all at once out
+    capi.check(eng.lib.aoadmm_state_get(eng.h, capi.F_FAC, 1, capi.ALL_SLABS, capi.dptr(packed), rows, R))
+    assert np.array_equal(packed, np.concatenate([c.ravel(order='F') for c in cells]))
+    packed2 = rng.standard_normal(rows * R)                              # all at once in, slab by slab out
+    capi.check(eng.lib.aoadmm_state_set(eng.h, capi.F_FAC, 1, capi.ALL_SLABS, capi.dptr(packed2), rows, R))
+    o = 0
+    for k, c in enumerate(cells):
+        got = np.zeros(c.shape, order='F')
+        capi.check(eng.lib.aoadmm_state_get(eng.h, capi.F_FAC, 1, k, capi.dptr(got), c.shape[0], R))
+        assert np.array_equal(got.ravel(order='F'), packed2[o:o + c.size])
+        o += c.size
+    with pytest.raises(Exception):                                        # wrong total row count is rejected
+        capi.check(eng.lib.aoadmm_state_set(eng.h, capi.F_FAC, 1, capi.ALL_SLABS, capi.dptr(packed2), rows - 1, R))
