@@ -146,6 +146,10 @@ int aoadmm_synchronize(aoadmm_ctx* ctx);
  * are replicated and only MTTKRP partials cross xGMI. */
 int aoadmm_comm_unique_id(char id[128]);
 int aoadmm_comm_init_rank(aoadmm_ctx* ctx, const char id[128], int rank, int world);
+/* Bring-up/test transport: `world` contexts driven by threads of ONE process (on one device or several) form
+ * group `key`; collectives go through host staging in rank order.  It lets the sharded data path run with
+ * world > 1 on a single GPU, which RCCL refuses.  Every rank must make the same sequence of library calls. */
+int aoadmm_comm_init_local(aoadmm_ctx* ctx, int key, int rank, int world);
 int aoadmm_comm_rank(aoadmm_ctx* ctx, int* rank, int* world);
 
 /* ---- model (the struct Z) ---------------------------------------------- */

@@ -97,6 +97,10 @@ int aoadmm_comm_init_rank(aoadmm_ctx* ctx, const char id[128], int rank, int wor
   CTX_OR_FAIL(ctx);
   return guarded([&] { ctx->eng->comm_init(id, rank, world); });
 }
+int aoadmm_comm_init_local(aoadmm_ctx* ctx, int key, int rank, int world) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->comm_init_local(key, rank, world); });
+}
 int aoadmm_comm_rank(aoadmm_ctx* ctx, int* rank, int* world) {
   CTX_OR_FAIL(ctx);
   return guarded([&] {

@@ -129,6 +129,8 @@ struct KernelStats {
   int64_t launches = 0;
 };
 
+struct LocalGroup;
+
 class Engine {
  public:
   explicit Engine(int device);
@@ -166,6 +168,8 @@ class Engine {
 
   // communicator
   void comm_init(const char id[128], int rank, int world);
+  void comm_init_local(int key, int rank, int world);
+  bool sharded() const { return comm_ != nullptr || local_ != nullptr; }
   int rank() const { return rank_; }
   int world() const { return world_; }
 
@@ -226,6 +230,7 @@ class Engine {
   KernelStats kstats_[2];   // [0] streaming contraction, [1] leading-mode contraction
   bool profile_ = true;
   ncclComm_t comm_ = nullptr;
+  std::shared_ptr<LocalGroup> local_;   // process-local group (threads of one process), see solver.hip
   int rank_ = 0, world_ = 1;
 
   AdmmCtl* ctl_of_mode(int m) { return ctls_.as<AdmmCtl>() + m; }

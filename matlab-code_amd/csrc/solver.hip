@@ -11,7 +11,10 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <set>
 
 namespace aoadmm {
@@ -52,6 +55,7 @@ void Engine::comm_init(const char id[128], int rank, int world) {
   AO_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world %d/%d", rank, world);
   AO_HIP(hipSetDevice(device_));
   if (comm_) { (void)ncclCommDestroy(comm_); comm_ = nullptr; }
+  local_.reset();
   if (id != nullptr) {               // world == 1 with an id: one-rank communicator (exercises the RCCL path on one GPU)
     ncclUniqueId uid;
     static_assert(sizeof(uid) <= 128, "unique id larger than the ABI buffer");
@@ -62,8 +66,71 @@ void Engine::comm_init(const char id[128], int rank, int world) {
   world_ = world;
 }
 
+// Process-local group: engines driven by threads of ONE process (on one device or several) meet at a
+// mutex/condvar barrier and add their buffers through host staging, in rank order, so every rank gets the same
+// bits.  It exists so the sharded data path (row blocks, own-rows buffers, objective partial sums) can be run with
+// world > 1 on a one-GPU box, where RCCL refuses two ranks on one device.  Not a transport for production: the
+// data crosses PCIe twice per collective.
+struct LocalGroup {
+  std::mutex m;
+  std::condition_variable cv;
+  int world = 0, arrived = 0, joined = 0;
+  uint64_t gen = 0;
+  std::vector<std::vector<double>> stage;     // one host buffer per rank
+  void barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    const uint64_t g = gen;
+    if (++arrived == world) {
+      arrived = 0;
+      ++gen;
+      cv.notify_all();
+      return;
+    }
+    if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g; }))
+      throw Error(AOADMM_ERR_RCCL, "local group: a rank did not reach the collective within 120 s");
+  }
+};
+static std::mutex g_groups_mutex;
+static std::map<int, std::shared_ptr<LocalGroup>> g_groups;
+
+void Engine::comm_init_local(int key, int rank, int world) {
+  AO_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world %d/%d", rank, world);
+  if (comm_) { (void)ncclCommDestroy(comm_); comm_ = nullptr; }
+  std::lock_guard<std::mutex> lk(g_groups_mutex);
+  std::shared_ptr<LocalGroup>& g = g_groups[key];
+  if (!g || g->joined == g->world) {           // first rank of a new (or re-used) key
+    g = std::make_shared<LocalGroup>();
+    g->world = world;
+    g->stage.resize(world);
+  }
+  AO_REQUIRE(g->world == world, "local group %d was created for %d ranks, not %d", key, g->world, world);
+  g->joined++;
+  local_ = g;
+  rank_ = rank;
+  world_ = world;
+}
+
 void Engine::allreduce(double* buf, int64_t n) {
-  if (!comm_ || n <= 0) return;
+  if (n <= 0) return;
+  if (local_) {
+    LocalGroup& g = *local_;
+    std::vector<double>& mine = g.stage[rank_];
+    mine.resize((size_t)n);
+    AO_HIP(hipMemcpyAsync(mine.data(), buf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    AO_HIP(hipStreamSynchronize(stream_));
+    g.barrier();                                // every rank has staged its contribution
+    std::vector<double> tot((size_t)n, 0.0);
+    for (int r = 0; r < g.world; ++r) {
+      AO_REQUIRE((int64_t)g.stage[r].size() == n, "local group: rank %d brought %lld values, rank %d brought %lld", r,
+                 (long long)g.stage[r].size(), rank_, (long long)n);
+      for (int64_t i = 0; i < n; ++i) tot[i] += g.stage[r][i];
+    }
+    g.barrier();                                // every rank has read all contributions
+    AO_HIP(hipMemcpyAsync(buf, tot.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream_));
+    AO_HIP(hipStreamSynchronize(stream_));
+    return;
+  }
+  if (!comm_) return;
   AO_NCCL(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, comm_, stream_));
 }
 
@@ -552,7 +619,7 @@ void Engine::em_pass_enqueue(int p, int update) {
   const ModeInfo& m1 = modes_[t.modes[1]];
   EmCpArgs a;
   a.X = b.X.data.p; a.mask = b.mask.as<uint8_t>();
-  a.A = m0.fac.d() + (comm_ ? b.row0 : 0); a.ldA = m0.rows;
+  a.A = m0.fac.d() + (sharded() ? b.row0 : 0); a.ldA = m0.rows;
   a.B = m1.fac.d(); a.ldB = m1.rows;
   a.C = nullptr; a.ldC = 0;
   a.I = b.dims[0]; a.Ipad = b.X.pad0; a.J = b.dims[1]; a.K = 1; a.R = m0.R; a.update = update;
@@ -566,7 +633,7 @@ void Engine::em_pass_enqueue(int p, int update) {
     // same imputation on the transposed copy (roles of the two factors swapped); its statistics are discarded
     EmCpArgs at = a;
     at.X = b.Xt.data.p; at.mask = b.maskT.as<uint8_t>();
-    at.A = m1.fac.d(); at.ldA = m1.rows; at.B = m0.fac.d() + (comm_ ? b.row0 : 0); at.ldB = m0.rows;
+    at.A = m1.fac.d(); at.ldA = m1.rows; at.B = m0.fac.d() + (sharded() ? b.row0 : 0); at.ldB = m0.rows;
     at.I = b.dims[1]; at.Ipad = b.Xt.pad0; at.J = b.dims[0];
     const size_t wsb = em_cp_ws_bytes(at.Ipad, 1);
     emws_.ensure(wsb + 64);
@@ -796,7 +863,7 @@ void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int 
   if (c == 2) pl = make_plan(1, 0, Ip * J, Ip * J, K, R, prec);
   else if (c == 1) pl = make_plan(K, Ip * J, Ip, Ip, J, R, prec);
   else {
-    Fc = facs[0].p + (comm_ ? b.row0 : 0);
+    Fc = facs[0].p + (sharded() ? b.row0 : 0);
     static const bool force_ldskernel = getenv("AOADMM_LEAD_KERNEL") != nullptr;   // development switch
     if (!force_ldskernel && ensure_permuted_copy(b)) {
       // Xp(j,k,i): mode 1 is the trailing index with stride Jp*K -> the register-streaming contraction
@@ -840,7 +907,7 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
   AO_REQUIRE(pos >= 0 && pos < b.nd, "mttkrp: mode %d out of range", pos);
   const int prec = b.X.prec;
   const int64_t I = b.dims[0], Ip = b.X.pad0;
-  const bool sharded = comm_ != nullptr;
+  const bool sharded = this->sharded();
   double* out_local = out;
   const int64_t out_rows_full = (pos == 0) ? b.full0 : b.dims[pos];
   if (sharded && pos == 0) {

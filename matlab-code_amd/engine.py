@@ -82,6 +82,10 @@ class Engine:
     def comm_init_rank(self, uid, rank, world):
         capi.check(self.lib.aoadmm_comm_init_rank(self.h, uid, int(rank), int(world)))
 
+    def comm_init_local(self, key, rank, world):
+        """Bring-up/test transport: engines driven by threads of this process form group `key` (see aoadmm_hip.h)."""
+        capi.check(self.lib.aoadmm_comm_init_local(self.h, int(key), int(rank), int(world)))
+
     # ---- op level -----------------------------------------------------------------
     def mttkrp(self, X, U, n, precision='f64'):
         """`mttkrp(X,U,n)` with 0-based n (cmtf_fun_AOADMM.m:97)."""

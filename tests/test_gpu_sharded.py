@@ -1,0 +1,101 @@
+"""The N > 1 data path with world > 1 on ONE GPU: every rank is a thread of this process with its own engine and
+stream, joined by the library's process-local group (aoadmm_comm_init_local: host-staged, rank-ordered sums in
+place of ncclAllReduce -- RCCL refuses two ranks on one device).  Everything else is the code the RCCL ranks run:
+mode-1 row blocks (csrc/solver.hip tensor_upload), zero-filled own-rows MTTKRP buffers, all-reduced partial
+objective sums, replicated ADMM.  Bars: all ranks bit-identical; factors within 1e-8 of the oracle (fp64)."""
+import copy
+import itertools
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import aoadmm as OA
+from helpers import cp_model, options, rel_fro, script1_model, script3_model
+from test_gpu_solver import compare, compare_par2, _with_mask, _compare_em
+
+pytestmark = pytest.mark.gpu
+_keys = itertools.count(1000)
+
+
+def run_sharded(pkg, Z, io, opt, world, seed=7, precision='f64'):
+    rng = np.random.default_rng(seed)
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=rng)
+    _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
+    key = next(_keys)
+    res, err = [None] * world, [None] * world
+
+    def rank_main(r):
+        try:
+            with pkg.Engine(0) as e:
+                e.comm_init_local(key, r, world)
+                _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=e, precision=precision)
+                res[r] = (Fg, og)
+        except BaseException as ex:   # noqa: BLE001 -- reported by the main thread
+            err[r] = ex
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for r, ex in enumerate(err):
+        assert ex is None, 'rank %d: %r' % (r, ex)
+    F0, o0 = res[0]
+    for r in range(1, world):                       # replicated state must be the same bits on every rank
+        Fr, orr = res[r]
+        for key_ in ('fac', 'constraint_fac', 'constraint_dual_fac'):
+            for a, b in zip(F0[key_], Fr[key_]):
+                if a is None:
+                    continue
+                if isinstance(a, (list, tuple)):
+                    assert all(np.array_equal(x, y) for x, y in zip(a, b)), (key_, r)
+                else:
+                    assert np.array_equal(a, b), (key_, r)
+        assert np.array_equal(o0['func_val_conv'], orr['func_val_conv'])
+    return Fo, oo, F0, o0
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_cp_tv_nonneg(pkg, world):
+    """config 5's model at oracle size; 37 rows over 2 or 3 ranks gives ragged blocks (19+18, 13+13+11)."""
+    rng = np.random.default_rng(21)
+    Z, io, _ = cp_model((37, 14, 12), 3, rng, [('TV regularization', 0.01), ('non-negativity',), ('non-negativity',)])
+    compare(*run_sharded(pkg, Z, io, options(MaxOuterIters=8), world))
+
+
+def test_sharded_fp32_tensor(pkg):
+    rng = np.random.default_rng(22)
+    Z, io, _ = cp_model((70, 33, 20), 4, rng, [('TV regularization', 0.01), ('non-negativity',), ('non-negativity',)])
+    Fo, oo, Fg, og = run_sharded(pkg, Z, io, options(MaxOuterIters=5), 2, precision='f32')
+    for a, b in zip(Fo['fac'], Fg['fac']):
+        assert rel_fro(b, a) < 1e-4
+
+
+def test_sharded_script3_partial_coupling(pkg):
+    """config 3: matrix + CP tensor, coupling type 4; both blocks row-sharded along their first mode."""
+    rng = np.random.default_rng(4)
+    Z, io = script3_model(rng)
+    compare(*run_sharded(pkg, Z, io, options(MaxOuterIters=10), 2))
+
+
+def test_sharded_cp_with_replicated_parafac2(pkg):
+    """config 1: the CP block is row-sharded, the PARAFAC2 block coupled to it is repeated on every rank."""
+    rng = np.random.default_rng(12)
+    Z, io = script1_model(rng, dims=(20, 30, 40))
+    compare_par2(*run_sharded(pkg, Z, io, options(MaxOuterIters=6), 2))
+
+
+def test_sharded_em_missing(pkg):
+    rng = np.random.default_rng(31)
+    Z, io, _ = cp_model((37, 22, 19), 3, rng, [('non-negativity',), ('non-negativity',), ('TV regularization', 1e-3)])
+    Z = _with_mask(Z, rng)
+    Fo, oo, Fg, og = run_sharded(pkg, Z, io, options(MaxOuterIters=8), 2)
+    compare(Fo, oo, Fg, og)
+    _compare_em(oo, og)
+
+
+def test_sharded_four_way(pkg):
+    rng = np.random.default_rng(91)
+    Z, io, _ = cp_model((12, 9, 8, 7), 3, rng, [('non-negativity',), None, ('l2-ball', 1.0), ('non-negativity',)])
+    compare(*run_sharded(pkg, Z, io, options(MaxOuterIters=6), 2))
