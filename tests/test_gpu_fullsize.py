@@ -121,3 +121,54 @@ def test_fp32_leading_mode_contraction_path(pkg, eng, dims, R):
     for a, b, c in zip(outs[0]['fac'], outs[1]['fac'], Fo['fac']):
         assert rel_fro(a, b) < 3e-5      # two fp32 summation orders, amplified by 6 iterations at R up to 33
         assert rel_fro(a, c) < 1e-4
+
+
+def test_config5_2000cube_sharded_over_two_ranks_equals_one(pkg):
+    """config 5 at full size (2000^3, R = 20, fp32 tensor, TV + non-negativity) on ONE engine and row-sharded over
+    TWO ranks (threads joined by the process-local group, tests/test_gpu_sharded.py): the device generator must
+    produce the same tensor under both partitions and three outer iterations must give the same factors.
+    Mode-1 rows never mix across ranks; modes 2 and 3 add the two ranks' partial sums in a different order than
+    one rank does, hence 1e-6 rather than bit equality."""
+    import threading
+    n, R = 2000, 20
+    base = dict(loss_function=['Frobenius'], model=['CP'], modes=[[1, 2, 3]], size=[n] * 3,
+                coupling=dict(lin_coupled_modes=[0, 0, 0], coupling_type=[], coupl_trafo_matrices=[None] * 3),
+                constrained_modes=[1, 1, 1],
+                constraints=[('TV regularization', 0.001), ('non-negativity',), ('non-negativity',)], weights=[1.0],
+                object=[dict(synthetic=True, rank=R, seed=3, noise=0.05)], _ranks=[R] * 3)
+    opt = dict(MaxOuterIters=3, MaxInnerIters=5, AbsFuncTol=0.0, OuterRelTol=0.0, innerRelPrTol_coupl=0.0,
+               innerRelPrTol_constr=0.0, innerRelDualTol_coupl=0.0, innerRelDualTol_constr=0.0, bsum=0)
+
+    def solve(e, Z, store, slot):
+        rng = np.random.default_rng(1)
+        io = dict(lambdas_init=[[1] * R], nvecs=0, distr=[lambda a, b: rng.random((a, b))] * 3, normalize=1)
+        pkg.build_model(e, Z, 'f32')
+        G = pkg.init_coupled_AOADMM_CMTF(Z, io, rng=rng, engine=e)
+        pkg.upload_state(e, Z, G)
+        out = pkg.run_solver(e, opt, 3)
+        store[slot] = (pkg.download_state(e, Z, G), out)
+
+    one = [None]
+    with pkg.Engine(0) as e:
+        solve(e, copy.deepcopy(base), one, 0)
+    two, err = [None, None], [None, None]
+
+    def rank_main(r):
+        try:
+            with pkg.Engine(0) as e:
+                e.comm_init_local(5000, r, 2)
+                solve(e, copy.deepcopy(base), two, r)
+        except BaseException as ex:   # noqa: BLE001
+            err[r] = ex
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert err == [None, None], err
+    for a, b in zip(two[0][0]['fac'], two[1][0]['fac']):
+        assert np.array_equal(a, b)                                  # replicated factors: same bits on both ranks
+    for a, b in zip(one[0][0]['fac'], two[0][0]['fac']):
+        assert rel_fro(b, a) < 1e-6
+    assert np.allclose(one[0][1]['func_val_conv'], two[0][1]['func_val_conv'], rtol=1e-6)
