@@ -114,7 +114,11 @@ typedef struct aoadmm_options {
   int32_t no_permuted_copy;              /* engine option: 1 = do not keep the second, mode-permuted resident copy of
                                             3-way tensors (saves the tensor's size in HBM, mode-1 contractions then
                                             use the LDS-transposed kernel); 0 = default */
-  int32_t reserved[6];
+  int32_t par2_slab_sharding;            /* engine option, with a communicator: 0 = auto (a PARAFAC2 block is repeated
+                                            on every rank unless it has >= 1024 slabs per rank), 1 = shard the slabs
+                                            over the ranks, -1 = never.  Blocks with Z.miss or the tPARAFAC2 constraint
+                                            are always repeated */
+  int32_t reserved[5];
 } aoadmm_options;
 
 /* `out` struct of cmtf_fun_AOADMM.m:480-494.  Arrays are caller-allocated with

@@ -56,7 +56,7 @@ class Options(C.Structure):
         ('bsum', C.c_int32), ('bsum_weight', C.c_double),
         ('iter_start_PAR2Bkconstraint', C.c_int32), ('has_increase_factor_rhoBk', C.c_int32),
         ('increase_factor_rhoBk', C.c_double), ('use_dimtree', C.c_int32), ('no_permuted_copy', C.c_int32),
-        ('reserved', C.c_int32 * 6),
+        ('par2_slab_sharding', C.c_int32), ('reserved', C.c_int32 * 5),
     ]
 
 

@@ -5,6 +5,8 @@
 // All kernels run one workgroup per slab; sizes are small (cfg4: I=40, J_k<=120, R=3, K=256), so these
 // are latency-bound and plain fp64 VALU code.
 #pragma once
+#include <functional>
+
 #include "admm.h"
 #include "common.h"
 #include "small.h"
@@ -17,7 +19,10 @@ struct P2Dims {
   const int64_t* off_h; // the same on the host
   int64_t Jtot;
   int Jmax;
+  int k0, k1;           // slabs this rank works on: [k0, k1) = [0, K) unless the block is slab-sharded
 };
+// all-reduce hook for slab-sharded blocks (Engine::allreduce on the library's stream)
+using P2AllReduce = std::function<void(double*, int64_t)>;
 
 // T1[k] = X_k * B_k  (I x R each)
 void par2_xkb(const double* X, const double* B, const P2Dims& d, double* T1, hipStream_t s);
@@ -42,19 +47,24 @@ struct P2BArgs {
   int use_constr;
 };
 // one inner iteration of ADMM_B_Parafac2 up to (not including) the constraint update   (:525-547, :582-585)
-void par2_b_iteration(const P2BArgs& a, const P2Dims& d, const AdmmCtl* ctl, hipStream_t s);
+// psum (R*R+1 doubles) != nullptr: slabs are sharded, DeltaB's sums go through `allreduce`
+void par2_b_iteration(const P2BArgs& a, const P2Dims& d, const AdmmCtl* ctl, hipStream_t s, double* psum,
+                      const P2AllReduce& allreduce);
 // Z_k = prox(B_k + muZ_k, rho_k) ; muZ_k += B_k - Z_k ; norms[k][4..6] = ||B-Z||^2, ||muZ||^2, ||Z-Zold||^2   (:566-579)
 void par2_b_constraint(const ProxSpec& ps, const double* B, double* Z, double* muZ, double* Zold, double* V,
                        const double* rho, const P2Dims& d, double* prox_ws, double* norms, const AdmmCtl* ctl,
                        hipStream_t s);
 // residual averages over the slabs + loop condition (:520, :558-585)
-void par2_b_finalize(const double* norms, int K, int use_constr, AdmmCtl* ctl, int max_inner, double tol_pr_coupl,
-                     double tol_pr_constr, double tol_du_coupl, double tol_du_constr, hipStream_t s);
+void par2_b_finalize(const double* norms, const P2Dims& d, int use_constr, AdmmCtl* ctl, int max_inner,
+                     double tol_pr_coupl, double tol_pr_constr, double tol_du_coupl, double tol_du_constr, hipStream_t s,
+                     double* part4, const P2AllReduce& allreduce);
 
 // mode C: a(k,r) = w * sum_i A(i,r) T1[k](i,r) ; C_k = GA .* GB[k] ; rho_k ; B_k (+rho_k/2 I if constrained) ; chol  (:221-240)
 void par2_c_system(const double* A, const double* T1, const double* GA, const double* GB, double w, double ridge,
                    double bsum_half, int constrained, const P2Dims& d, const double* Cfac, double* a, double* rho,
-                   double* rhomax, double* L, AdmmCtl* ctl, hipStream_t s);
+                   double* L, AdmmCtl* ctl, hipStream_t s);
+// rhomax = max_k rho_k (:1424); separate because a slab-sharded block gathers rho first
+void par2_rho_max(const double* rho, int K, double* rhomax, hipStream_t s);
 // row k: rhs = a_k (+ rho_k/2 (Z(k,:) - mu(k,:))) ; C(k,:) = L_k'\(L_k\rhs)      (:236, :604-605)
 void par2_c_rowsolve(const double* a, const double* rho, const double* L, const double* Z, const double* mu,
                      int use_admm, const P2Dims& d, double* Cfac, const AdmmCtl* ctl, hipStream_t s);
@@ -67,5 +77,8 @@ void par2_reg_values(const double* B, int type, double eta, const P2Dims& d, dou
 // q[k][0..3] = ||B_k - P_k DeltaB||^2, ||B_k||^2, ||B_k - Z_k||^2 (Z nullable), 0          (:1355, :1337)
 void par2_b_gaps(const double* B, const double* P, const double* DeltaB, const double* Z, const P2Dims& d,
                  double* q, hipStream_t s);
+
+// out[0] = 1 if any of the three loop-control records carries the not-positive-definite flag
+void par2_collect_notpd(const AdmmCtl* a, const AdmmCtl* b, const AdmmCtl* c, double* out, hipStream_t s);
 
 }  // namespace aoadmm

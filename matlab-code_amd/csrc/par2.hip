@@ -12,7 +12,7 @@ static constexpr int kP2Threads = 64;
 
 // ---------------------------------------------------------------------------
 __global__ void par2_xkb_k(const double* X, const double* B, P2Dims d, double* T1) {
-  const int k = blockIdx.x;
+  const int k = d.k0 + blockIdx.x;
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   const double* Xk = X + (int64_t)d.I * o;
@@ -25,12 +25,12 @@ __global__ void par2_xkb_k(const double* X, const double* B, P2Dims d, double* T
   }
 }
 void par2_xkb(const double* X, const double* B, const P2Dims& d, double* T1, hipStream_t s) {
-  par2_xkb_k<<<d.K, 128, 0, s>>>(X, B, d, T1);
+  par2_xkb_k<<<d.k1 - d.k0, 128, 0, s>>>(X, B, d, T1);
   AO_KERNEL_CHECK();
 }
 
 __global__ void par2_gram_k(const double* B, P2Dims d, double* GB) {
-  const int k = blockIdx.x;
+  const int k = d.k0 + blockIdx.x;
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   const double* Bk = B + o * d.R;
@@ -42,7 +42,7 @@ __global__ void par2_gram_k(const double* B, P2Dims d, double* GB) {
   }
 }
 void par2_gram(const double* B, const P2Dims& d, double* GB, hipStream_t s) {
-  par2_gram_k<<<d.K, kP2Threads, 0, s>>>(B, d, GB);
+  par2_gram_k<<<d.k1 - d.k0, kP2Threads, 0, s>>>(B, d, GB);
   AO_KERNEL_CHECK();
 }
 
@@ -51,10 +51,10 @@ void par2_gram(const double* B, const P2Dims& d, double* GB, hipStream_t s) {
 // does not depend on scheduling.  The value is returned in the threads of group 0.
 constexpr int kKsumThreads = 256;
 template <class F>
-__device__ inline double ksum_tile(bool live, int g, int ng, int ew, int K, double* red, F f) {
+__device__ inline double ksum_tile(bool live, int g, int ng, int ew, int k0, int k1, double* red, F f) {
   double acc = 0.0;
   if (live)
-    for (int k = g; k < K; k += ng) acc += f(k);
+    for (int k = k0 + g; k < k1; k += ng) acc += f(k);
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int s = ng >> 1; s > 0; s >>= 1) {
@@ -77,13 +77,13 @@ __global__ __launch_bounds__(kKsumThreads) void par2_modeA_combine_k(const doubl
   if (blockIdx.x * ew < nA) {            // tiles never straddle nA: the host rounds nA up to a tile boundary
     const bool lv = e < nA;
     const int r = lv ? e / d.I : 0;
-    v = ksum_tile(lv, g, ng, ew, K, red, [&](int k) { return T1[(int64_t)k * nA + e] * Cfac[k + K * r]; });
+    v = ksum_tile(lv, g, ng, ew, d.k0, d.k1, red, [&](int k) { return T1[(int64_t)k * nA + e] * Cfac[k + K * r]; });
     if (lv && g == 0) Amt[e] = v;
   } else {
     const int f = e - (int)((nA + ew - 1) / ew) * ew;
     const bool lv = f < nC;
     const int r = lv ? f % d.R : 0, q = lv ? f / d.R : 0;
-    v = ksum_tile(lv, g, ng, ew, K, red,
+    v = ksum_tile(lv, g, ng, ew, d.k0, d.k1, red,
                   [&](int k) { return Cfac[k + K * r] * GB[(int64_t)k * nC + f] * Cfac[k + K * q]; });
     if (lv && g == 0) Csys[f] = v;
   }
@@ -98,7 +98,7 @@ void par2_modeA_combine(const double* T1, const double* Cfac, const double* GB, 
 }
 
 __global__ void par2_xta_k(const double* X, const double* A, const double* Cfac, double w, P2Dims d, double* Ak) {
-  const int k = blockIdx.x;
+  const int k = d.k0 + blockIdx.x;
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   const double* Xk = X + (int64_t)d.I * o;
@@ -112,7 +112,7 @@ __global__ void par2_xta_k(const double* X, const double* A, const double* Cfac,
 }
 void par2_xta(const double* X, const double* A, const double* Cfac, double w, const P2Dims& d, double* Ak,
               hipStream_t s) {
-  par2_xta_k<<<d.K, 128, 0, s>>>(X, A, Cfac, w, d, Ak);
+  par2_xta_k<<<d.k1 - d.k0, 128, 0, s>>>(X, A, Cfac, w, d, Ak);
   AO_KERNEL_CHECK();
 }
 
@@ -120,7 +120,7 @@ __global__ void par2_b_system_k(const double* GA, const double* Cfac, double w, 
                                 double rho_scale, int nrho, P2Dims d, double* rho, double* L, AdmmCtl* ctl) {
   extern __shared__ double sh[];
   __shared__ double rk;
-  const int k = blockIdx.x, R = d.R;
+  const int k = d.k0 + blockIdx.x, R = d.R;
   for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
     const int r = e % R, q = e / R;
     sh[e] = Cfac[k + d.K * r] * GA[e] * Cfac[k + d.K * q];           // C_k = D_k (A'A) D_k   (:194)
@@ -146,7 +146,7 @@ __global__ void par2_b_system_k(const double* GA, const double* Cfac, double w, 
 }
 void par2_b_system(const double* GA, const double* Cfac, double w, double ridge, double bsum_half, double rho_scale,
                    int nrho, const P2Dims& d, double* rho, double* L, AdmmCtl* ctl, hipStream_t s) {
-  par2_b_system_k<<<d.K, kP2Threads, (size_t)d.R * d.R * sizeof(double), s>>>(GA, Cfac, w, ridge, bsum_half, rho_scale,
+  par2_b_system_k<<<d.k1 - d.k0, kP2Threads, (size_t)d.R * d.R * sizeof(double), s>>>(GA, Cfac, w, ridge, bsum_half, rho_scale,
                                                                             nrho, d, rho, L, ctl);
   AO_KERNEL_CHECK();
 }
@@ -158,7 +158,7 @@ void par2_b_system(const double* GA, const double* Cfac, double w, double ridge,
 __global__ void par2_b_primal_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
   extern __shared__ double sh[];          // L_k (R*R) then DeltaB (R*R)
-  const int k = blockIdx.x, R = d.R;
+  const int k = d.k0 + blockIdx.x, R = d.R;
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   double* Lsh = sh;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kP2Threads) void par2_polar_k(double* W, double* P,
                                                             int in_lds) {
   CTL_GUARD(ctl);
   extern __shared__ double Jr[];          // R*R, then W_k (n*R) when in_lds
-  const int k = blockIdx.x, R = d.R, lane = threadIdx.x;
+  const int k = d.k0 + blockIdx.x, R = d.R, lane = threadIdx.x;
   const int64_t o = d.off[k];
   const int n = (int)(d.off[k + 1] - o);
   double* Pk = P + o * R;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kP2Threads) void par2_polar_k(double* W, double* P,
 // part[k] = rho_k * P_k' * (B_k + mu_k)   (:541)
 __global__ void par2_deltab_part_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
-  const int k = blockIdx.x, R = d.R;
+  const int k = d.k0 + blockIdx.x, R = d.R;
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   const int64_t base = o * R;
@@ -286,22 +286,35 @@ __global__ void par2_deltab_part_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
     a.part[(int64_t)k * R * R + e] = a.rho[k] * acc;
   }
 }
-// DeltaB_old = DeltaB ; DeltaB = sum_k part[k] / sum_k rho_k   (:537-544)
-__global__ __launch_bounds__(kKsumThreads) void par2_deltab_combine_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl, int ew) {
+// DeltaB_old = DeltaB ; DeltaB = sum_k part[k] / sum_k rho_k   (:537-544).  With slabs sharded over ranks
+// (psum != nullptr) the kernel leaves this rank's partial sums psum[0..R*R) and psum[R*R] = sum rho_k; after the
+// all-reduce par2_deltab_apply_k finishes the division.
+__global__ __launch_bounds__(kKsumThreads) void par2_deltab_combine_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl, int ew,
+                                                                       double* psum) {
   CTL_GUARD(ctl);
   __shared__ double red[kKsumThreads];
   __shared__ double red2[kKsumThreads];
-  const int R = d.R, K = d.K;
+  const int R = d.R;
   double sr = 0.0;
-  for (int k = threadIdx.x; k < K; k += kKsumThreads) sr += a.rho[k];
+  for (int k = d.k0 + threadIdx.x; k < d.k1; k += kKsumThreads) sr += a.rho[k];
   sr = block_sum_pow2(sr, red2);
   const int ng = kKsumThreads / ew, ex = threadIdx.x % ew, g = threadIdx.x / ew;
   const int e = blockIdx.x * ew + ex;
   const bool lv = e < R * R;
-  const double acc = ksum_tile(lv, g, ng, ew, K, red, [&](int k) { return a.part[(int64_t)k * R * R + e]; });
-  if (lv && g == 0) {
+  const double acc = ksum_tile(lv, g, ng, ew, d.k0, d.k1, red, [&](int k) { return a.part[(int64_t)k * R * R + e]; });
+  if (psum) {
+    if (lv && g == 0) psum[e] = acc;
+    if (blockIdx.x == 0 && threadIdx.x == 0) psum[R * R] = sr;
+  } else if (lv && g == 0) {
     a.DeltaBold[e] = a.DeltaB[e];
     a.DeltaB[e] = acc / sr;
+  }
+}
+__global__ void par2_deltab_apply_k(P2BArgs a, int R, const double* psum, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
+    a.DeltaBold[e] = a.DeltaB[e];
+    a.DeltaB[e] = psum[e] / psum[R * R];
   }
 }
 // mu_k += B_k - P_k*DeltaB (:546); norms[k] = ||B-P*D||^2, ||B||^2, ||Pold*Dold - P*D||^2, ||mu||^2 (:583-584)
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(kP2Threads) void par2_b_dual_k(P2BArgs a, P2Dims d,
   CTL_GUARD(ctl);
   extern __shared__ double sh2[];         // DeltaB, DeltaBold
   __shared__ double red[kP2Threads];
-  const int k = blockIdx.x, R = d.R;
+  const int k = d.k0 + blockIdx.x, R = d.R;
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   const int64_t base = o * R;
@@ -337,20 +350,27 @@ __global__ __launch_bounds__(kP2Threads) void par2_b_dual_k(P2BArgs a, P2Dims d,
   }
 }
 
-void par2_b_iteration(const P2BArgs& a, const P2Dims& d, const AdmmCtl* ctl, hipStream_t s) {
+void par2_b_iteration(const P2BArgs& a, const P2Dims& d, const AdmmCtl* ctl, hipStream_t s, double* psum,
+                      const P2AllReduce& allreduce) {
   const size_t rr = (size_t)d.R * d.R * sizeof(double);
-  par2_b_primal_k<<<d.K, kP2Threads, 2 * rr, s>>>(a, d, ctl);
+  const unsigned nk = (unsigned)(d.k1 - d.k0);
+  par2_b_primal_k<<<nk, kP2Threads, 2 * rr, s>>>(a, d, ctl);
   AO_KERNEL_CHECK();
   const size_t wl = (size_t)d.Jmax * d.R * sizeof(double);
   const int in_lds = rr + wl <= 48 * 1024;
-  par2_polar_k<<<d.K, kP2Threads, rr + (in_lds ? wl : 0), s>>>(a.W, a.P, d, ctl, in_lds);
+  par2_polar_k<<<nk, kP2Threads, rr + (in_lds ? wl : 0), s>>>(a.W, a.P, d, ctl, in_lds);
   AO_KERNEL_CHECK();
-  par2_deltab_part_k<<<d.K, kP2Threads, 0, s>>>(a, d, ctl);
+  par2_deltab_part_k<<<nk, kP2Threads, 0, s>>>(a, d, ctl);
   AO_KERNEL_CHECK();
   const int ew = ksum_tile_width((int64_t)d.R * d.R);
-  par2_deltab_combine_k<<<(unsigned)cdiv((int64_t)d.R * d.R, ew), kKsumThreads, 0, s>>>(a, d, ctl, ew);
+  par2_deltab_combine_k<<<(unsigned)cdiv((int64_t)d.R * d.R, ew), kKsumThreads, 0, s>>>(a, d, ctl, ew, psum);
   AO_KERNEL_CHECK();
-  par2_b_dual_k<<<d.K, kP2Threads, 2 * rr, s>>>(a, d, ctl);
+  if (psum) {
+    allreduce(psum, (int64_t)d.R * d.R + 1);          // every rank, whatever ctl says: the ranks must stay in step
+    par2_deltab_apply_k<<<1, 256, 0, s>>>(a, d.R, psum, ctl);
+    AO_KERNEL_CHECK();
+  }
+  par2_b_dual_k<<<nk, kP2Threads, 2 * rr, s>>>(a, d, ctl);
   AO_KERNEL_CHECK();
 }
 
@@ -368,7 +388,7 @@ __global__ __launch_bounds__(kP2Threads) void par2_bz_post_k(const double* B, co
                                                               const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
   __shared__ double red[kP2Threads];
-  const int k = blockIdx.x, R = d.R;
+  const int k = d.k0 + blockIdx.x, R = d.R;
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   const int64_t base = o * R;
@@ -424,35 +444,47 @@ __global__ void par2_tsmooth_k(const double* V, double* Z, const double* rho, do
 void par2_b_constraint(const ProxSpec& ps, const double* B, double* Z, double* muZ, double* Zold, double* V,
                        const double* rho, const P2Dims& d, double* prox_ws, double* norms, const AdmmCtl* ctl,
                        hipStream_t s) {
-  const int64_t n = d.Jtot * d.R;
+  const int64_t* off = d.off_h;
+  const int64_t e0 = off[d.k0] * d.R;                  // this rank's slabs are one contiguous range
+  const int64_t n = (off[d.k1] - off[d.k0]) * d.R;
   int64_t nb = cdiv(n, 256);
   if (nb > 1024) nb = 1024;
-  par2_bz_pre_k<<<(unsigned)nb, 256, 0, s>>>(B, Z, muZ, Zold, V, n, ctl);
+  par2_bz_pre_k<<<(unsigned)nb, 256, 0, s>>>(B + e0, Z + e0, muZ + e0, Zold + e0, V + e0, n, ctl);
   AO_KERNEL_CHECK();
   // Z_k = prox(B_k + muZ_k, rho_k) slab by slab (:568): every catalogue entry goes through prox_apply
-  const int64_t* off = d.off_h;
   if (ps.type == AOADMM_C_TPARAFAC2) {
     AO_REQUIRE(d.K <= kTsmoothMaxK, "tPARAFAC2 on the device supports up to %d slabs", kTsmoothMaxK);
+    AO_REQUIRE(d.k0 == 0 && d.k1 == d.K, "tPARAFAC2 couples neighbouring slabs: the block cannot be slab-sharded");
     const int64_t ne = off[1] * d.R;
     par2_tsmooth_k<<<(unsigned)cdiv(ne, 128), 128, 0, s>>>(V, Z, rho, ps.p0, d, ctl);
     AO_KERNEL_CHECK();
   } else
-  for (int k = 0; k < d.K; ++k) {
+  for (int k = d.k0; k < d.k1; ++k) {
     const int64_t Jk = off[k + 1] - off[k];
     prox_apply(ps, V + off[k] * d.R, Jk, Z + off[k] * d.R, Jk, Jk, d.R, rho + k, 1.0, prox_ws, ctl, s,
                Zold + off[k] * d.R, Jk);
   }
-  par2_bz_post_k<<<d.K, kP2Threads, 0, s>>>(B, Z, muZ, Zold, d, norms, ctl);
+  par2_bz_post_k<<<d.k1 - d.k0, kP2Threads, 0, s>>>(B, Z, muZ, Zold, d, norms, ctl);
   AO_KERNEL_CHECK();
 }
 
-__global__ __launch_bounds__(kKsumThreads) void par2_b_finalize_k(const double* norms, int K, int use_constr,
-                                                                   AdmmCtl* ctl, int max_inner, double tpc,
-                                                                   double tpz, double tdc, double tdz) {
+// Residual means over the slabs (:571-577, :583-584) and the loop condition (:520).  part4 != nullptr (slabs sharded
+// over ranks): leave this rank's share of the four means in part4; par2_b_finalize_apply_k decides after the all-reduce.
+__device__ inline void par2_b_decide(AdmmCtl* ctl, double pc, double pz, double dc, double dz, int max_inner, double tpc,
+                                     double tpz, double tdc, double tdz) {
+  ctl->res[0] = pc; ctl->res[1] = pz; ctl->res[2] = dc; ctl->res[3] = dz;
+  const int it = ctl->iters + 1;
+  ctl->iters = it;
+  ctl->active = (it < max_inner && (pc > tpc || pz > tpz || dc > tdc || dz > tdz)) ? 1 : 0;   // :520
+}
+__global__ __launch_bounds__(kKsumThreads) void par2_b_finalize_k(const double* norms, int K, int k0, int k1,
+                                                                   int use_constr, AdmmCtl* ctl, int max_inner,
+                                                                   double tpc, double tpz, double tdc, double tdz,
+                                                                   double* part4) {
   if (ctl->active == 0) return;
   __shared__ double red[kKsumThreads];
   double pc = 0, dc = 0, pz = 0, dz = 0;
-  for (int k = threadIdx.x; k < K; k += kKsumThreads) {
+  for (int k = k0 + threadIdx.x; k < k1; k += kKsumThreads) {
     const double* nk = norms + (int64_t)k * 8;
     const double nb = sqrt(nk[1]);
     pc += sqrt(nk[0]) / nb / K;                                 // :583
@@ -466,16 +498,26 @@ __global__ __launch_bounds__(kKsumThreads) void par2_b_finalize_k(const double* 
   pc = block_sum_pow2(pc, red); dc = block_sum_pow2(dc, red);
   pz = block_sum_pow2(pz, red); dz = block_sum_pow2(dz, red);
   if (threadIdx.x != 0) return;
-  ctl->res[0] = pc; ctl->res[1] = pz; ctl->res[2] = dc; ctl->res[3] = dz;
-  const int it = ctl->iters + 1;
-  ctl->iters = it;
-  ctl->active = (it < max_inner && (pc > tpc || pz > tpz || dc > tdc || dz > tdz)) ? 1 : 0;   // :520
+  if (part4) { part4[0] = pc; part4[1] = pz; part4[2] = dc; part4[3] = dz; return; }
+  par2_b_decide(ctl, pc, pz, dc, dz, max_inner, tpc, tpz, tdc, tdz);
 }
-void par2_b_finalize(const double* norms, int K, int use_constr, AdmmCtl* ctl, int max_inner, double tol_pr_coupl,
-                     double tol_pr_constr, double tol_du_coupl, double tol_du_constr, hipStream_t s) {
-  par2_b_finalize_k<<<1, kKsumThreads, 0, s>>>(norms, K, use_constr, ctl, max_inner, tol_pr_coupl, tol_pr_constr, tol_du_coupl,
-                                     tol_du_constr);
+__global__ void par2_b_finalize_apply_k(const double* part4, AdmmCtl* ctl, int max_inner, double tpc, double tpz,
+                                        double tdc, double tdz) {
+  if (ctl->active == 0 || threadIdx.x != 0) return;
+  par2_b_decide(ctl, part4[0], part4[1], part4[2], part4[3], max_inner, tpc, tpz, tdc, tdz);
+}
+void par2_b_finalize(const double* norms, const P2Dims& d, int use_constr, AdmmCtl* ctl, int max_inner,
+                     double tol_pr_coupl, double tol_pr_constr, double tol_du_coupl, double tol_du_constr, hipStream_t s,
+                     double* part4, const P2AllReduce& allreduce) {
+  par2_b_finalize_k<<<1, kKsumThreads, 0, s>>>(norms, d.K, d.k0, d.k1, use_constr, ctl, max_inner, tol_pr_coupl,
+                                               tol_pr_constr, tol_du_coupl, tol_du_constr, part4);
   AO_KERNEL_CHECK();
+  if (part4) {
+    allreduce(part4, 4);
+    par2_b_finalize_apply_k<<<1, 64, 0, s>>>(part4, ctl, max_inner, tol_pr_coupl, tol_pr_constr, tol_du_coupl,
+                                             tol_du_constr);
+    AO_KERNEL_CHECK();
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -486,7 +528,7 @@ __global__ void par2_c_system_k(const double* A, const double* T1, const double*
                                 double* a, double* rho, double* L, AdmmCtl* ctl) {
   extern __shared__ double sh[];
   __shared__ double rk;
-  const int k = blockIdx.x, R = d.R, I = d.I;
+  const int k = d.k0 + blockIdx.x, R = d.R, I = d.I;
   for (int r = threadIdx.x; r < R; r += blockDim.x) {
     double acc = 0.0;
     for (int i = 0; i < I; ++i) acc += A[i + I * r] * T1[(int64_t)k * I * R + i + I * r];
@@ -521,18 +563,20 @@ __global__ void par2_max_k(const double* x, int n, double* out) {
 }
 void par2_c_system(const double* A, const double* T1, const double* GA, const double* GB, double w, double ridge,
                    double bsum_half, int constrained, const P2Dims& d, const double* Cfac, double* a, double* rho,
-                   double* rhomax, double* L, AdmmCtl* ctl, hipStream_t s) {
-  par2_c_system_k<<<d.K, kP2Threads, (size_t)d.R * d.R * sizeof(double), s>>>(A, T1, GA, GB, w, ridge, bsum_half,
+                   double* L, AdmmCtl* ctl, hipStream_t s) {
+  par2_c_system_k<<<d.k1 - d.k0, kP2Threads, (size_t)d.R * d.R * sizeof(double), s>>>(A, T1, GA, GB, w, ridge, bsum_half,
                                                                             constrained, d, Cfac, a, rho, L, ctl);
   AO_KERNEL_CHECK();
-  par2_max_k<<<1, 64, 0, s>>>(rho, d.K, rhomax);
+}
+void par2_rho_max(const double* rho, int K, double* rhomax, hipStream_t s) {
+  par2_max_k<<<1, 64, 0, s>>>(rho, K, rhomax);
   AO_KERNEL_CHECK();
 }
 
 __global__ void par2_c_rowsolve_k(const double* a, const double* rho, const double* L, const double* Z,
                                   const double* mu, int use_admm, P2Dims d, double* Cfac, const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = d.k0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= d.K) return;
   const int R = d.R, K = d.K;
   const double* Lk = L + (int64_t)k * R * R;
@@ -566,7 +610,7 @@ void par2_c_rowsolve(const double* a, const double* rho, const double* L, const 
 __global__ __launch_bounds__(kP2Threads) void par2_residual_k(const double* X, const double* A, const double* B,
                                                                const double* Cfac, P2Dims d, double* res) {
   __shared__ double red[kP2Threads];
-  const int k = blockIdx.x, R = d.R, I = d.I;
+  const int k = d.k0 + blockIdx.x, R = d.R, I = d.I;
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   const double* Xk = X + (int64_t)I * o;
@@ -584,14 +628,14 @@ __global__ __launch_bounds__(kP2Threads) void par2_residual_k(const double* X, c
 }
 void par2_residual(const double* X, const double* A, const double* B, const double* Cfac, const P2Dims& d,
                    double* res, hipStream_t s) {
-  par2_residual_k<<<d.K, kP2Threads, 0, s>>>(X, A, B, Cfac, d, res);
+  par2_residual_k<<<d.k1 - d.k0, kP2Threads, 0, s>>>(X, A, B, Cfac, d, res);
   AO_KERNEL_CHECK();
 }
 
 __global__ __launch_bounds__(kP2Threads) void par2_b_gaps_k(const double* B, const double* P, const double* DeltaB,
                                                              const double* Z, P2Dims d, double* q) {
   __shared__ double red[kP2Threads];
-  const int k = blockIdx.x, R = d.R;
+  const int k = d.k0 + blockIdx.x, R = d.R;
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   const int64_t base = o * R;
@@ -615,7 +659,7 @@ __global__ __launch_bounds__(kP2Threads) void par2_b_gaps_k(const double* B, con
 // summed over the slabs at cmtf_fun_AOADMM.m:1279-1281).  One workgroup per slab, fixed summation order.
 __global__ __launch_bounds__(kP2Threads) void par2_reg_k(const double* B, int type, double eta, P2Dims d, double* regv) {
   __shared__ double red[kP2Threads];
-  const int k = blockIdx.x, R = d.R;
+  const int k = d.k0 + blockIdx.x, R = d.R;
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   const double* Bk = B + o * R;
@@ -645,13 +689,21 @@ __global__ __launch_bounds__(kP2Threads) void par2_reg_k(const double* B, int ty
   if (threadIdx.x == 0) regv[k] = eta * tot;
 }
 void par2_reg_values(const double* B, int type, double eta, const P2Dims& d, double* regv, hipStream_t s) {
-  par2_reg_k<<<d.K, kP2Threads, 0, s>>>(B, type, eta, d, regv);
+  par2_reg_k<<<d.k1 - d.k0, kP2Threads, 0, s>>>(B, type, eta, d, regv);
+  AO_KERNEL_CHECK();
+}
+
+__global__ void par2_collect_notpd_k(const AdmmCtl* a, const AdmmCtl* b, const AdmmCtl* c, double* out) {
+  out[0] = (a->notpd || b->notpd || c->notpd) ? 1.0 : 0.0;
+}
+void par2_collect_notpd(const AdmmCtl* a, const AdmmCtl* b, const AdmmCtl* c, double* out, hipStream_t s) {
+  par2_collect_notpd_k<<<1, 1, 0, s>>>(a, b, c, out);
   AO_KERNEL_CHECK();
 }
 
 void par2_b_gaps(const double* B, const double* P, const double* DeltaB, const double* Z, const P2Dims& d, double* q,
                  hipStream_t s) {
-  par2_b_gaps_k<<<d.K, kP2Threads, 0, s>>>(B, P, DeltaB, Z, d, q);
+  par2_b_gaps_k<<<d.k1 - d.k0, kP2Threads, 0, s>>>(B, P, DeltaB, Z, d, q);
   AO_KERNEL_CHECK();
 }
 

@@ -94,9 +94,20 @@ struct Par2Block {
   bool has_DeltaB = false;
   std::vector<char> have_P, have_mu;
   DevBuf W, T1, GB, Ak, Lk, rhok, part, norms, res, q, regv, Csys, ac, Lc, rhoc, rhomax;
+  // slab sharding over the ranks of a communicator (aoadmm_options.par2_slab_sharding): this rank runs the per-slab
+  // kernels on [k0, k1) only; every sum over k is all-reduced, slab-valued state is gathered when the solve ends
+  bool slab_sharded = false;
+  int k0 = 0, k1 = 0;
+  DevBuf psum;                    // R*R+1 partial sums of DeltaB, then 4 residual means
   P2Dims dims() const {
     P2Dims d;
     d.K = K; d.I = I; d.R = R; d.off = off_d.as<int64_t>(); d.off_h = off_h.data(); d.Jtot = Jtot; d.Jmax = Jmax;
+    d.k0 = slab_sharded ? k0 : 0; d.k1 = slab_sharded ? k1 : K;
+    return d;
+  }
+  P2Dims dims_all() const {       // every slab, whatever the sharding (replicated C-mode loop)
+    P2Dims d = dims();
+    d.k0 = 0; d.k1 = K;
     return d;
   }
 };
@@ -169,6 +180,7 @@ class Engine {
   // communicator
   void comm_init(const char id[128], int rank, int world);
   void comm_init_local(int key, int rank, int world);
+  void par2_gather_slabs(TensorInfo& t);
   bool sharded() const { return comm_ != nullptr || local_ != nullptr; }
   int rank() const { return rank_; }
   int world() const { return world_; }

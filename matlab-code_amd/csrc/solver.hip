@@ -1494,6 +1494,17 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     AO_REQUIRE(b.has_DeltaB, "G.DeltaB{%d} missing", p + 1);
     for (int k = 0; k < b.K; ++k) AO_REQUIRE(b.have_P[k] && b.have_mu[k], "G.P{%d}{%d} / G.mu_DeltaB{%d}{%d} missing", p + 1, k + 1, p + 1, k + 1);
     par2_ensure_work(t);
+    {
+      // slabs over the ranks or every slab on every rank (aoadmm_options.par2_slab_sharding)
+      const ModeInfo& mB = modes_[t.modes[1]];
+      const bool can = sharded() && world_ > 1 && !b.has_mask && !(mB.constrained && mB.prox.type == AOADMM_C_TPARAFAC2);
+      const bool want = opt.par2_slab_sharding > 0 || (opt.par2_slab_sharding == 0 && b.K / world_ >= 1024);
+      b.slab_sharded = can && want;
+      const int per = (int)cdiv(b.K, world_);
+      b.k0 = std::min(b.K, per * rank_);
+      b.k1 = std::min(b.K, b.k0 + per);
+      AO_REQUIRE(!b.slab_sharded || b.k1 > b.k0, "rank %d owns no slab of PARAFAC2 block %d (%d slabs, %d ranks)", rank_, p + 1, b.K, world_);
+    }
     par2_gram(modes_[t.modes[1]].fac.d(), b.dims(), b.GB.d(), stream_);      // :71-73
     t.last_pos = 2;
   }
@@ -1531,10 +1542,12 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
       const bool masked = t.par2 ? t.p2.has_mask : t.blk.has_mask;
       if (t.par2) {
         Par2Block& b = t.p2;
-        std::vector<double> res(b.K), q((size_t)b.K * 4);
-        AO_HIP(hipMemcpyAsync(res.data(), b.res.p, b.K * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        std::vector<double> res(b.K + 1, 0.0), q((size_t)b.K * 4);
+        AO_HIP(hipMemcpyAsync(res.data(), b.res.p, (b.K + (b.slab_sharded ? 1 : 0)) * sizeof(double), hipMemcpyDeviceToHost, stream_));
         AO_HIP(hipMemcpyAsync(q.data(), b.q.p, (size_t)b.K * 4 * sizeof(double), hipMemcpyDeviceToHost, stream_));
         AO_HIP(hipStreamSynchronize(stream_));
+        if (res[b.K] > 0)                           // some rank's slabs hit a non-positive-definite system
+          throw Error(AOADMM_ERR_NOT_PD, "Cholesky failed in a PARAFAC2 slab system on another rank (chol in cmtf_fun_AOADMM.m:212/240)");
         double fp = 0.0;
         if (masked) fp = hem[4 * p + 2];                                                        // :1249-1252
         else if (!eval_first && t.last_pos == 0) fp = t.normsq - 2.0 * (sp[0] / t.weight) + sp[1];   // :1254-1260
@@ -1687,6 +1700,9 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   }
   out->f_tensors = f[0]; out->f_couplings = f[1]; out->f_constraints = f[2]; out->f_PAR2_couplings = f[3];
   out->f_rel_missing = f_rel_missing;
+  for (int p = 0; p < n_tensors_; ++p)
+    if (tensors_[p].par2) par2_gather_slabs(tensors_[p]);
+  AO_HIP(hipStreamSynchronize(stream_));
   out->OuterIterations = iter - 1;
   out->exit_code = iter > opt.MaxOuterIters ? 0 : 1;                           // make_exit_flag.m:4-5
   for (int i = 0; i < 4; ++i) out->exit_abs[i] = f[i] < opt.AbsFuncTol ? 1 : 0;

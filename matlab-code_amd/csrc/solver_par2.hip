@@ -97,8 +97,9 @@ void Engine::par2_ensure_work(TensorInfo& t) {
   b.GB.ensure((size_t)b.K * RR); b.Lk.ensure((size_t)b.K * RR); b.Lc.ensure((size_t)b.K * RR);
   b.rhok.ensure((size_t)b.K * 8); b.rhoc.ensure((size_t)b.K * 8); b.rhomax.ensure(64);
   b.part.ensure((size_t)b.K * RR); b.norms.ensure((size_t)b.K * 8 * 8);
-  b.res.ensure((size_t)b.K * 8); b.q.ensure((size_t)b.K * 4 * 8); b.regv.ensure((size_t)b.K * 8);
+  b.res.ensure((size_t)(b.K + 1) * 8); b.q.ensure((size_t)b.K * 4 * 8); b.regv.ensure((size_t)b.K * 8);
   b.Csys.ensure(RR); b.ac.ensure((size_t)b.K * b.R * 8);
+  b.psum.ensure(RR + 128);                       // R*R+1 sums of DeltaB, then (at R*R+8) four residual means
   ModeInfo& mB = modes_[t.modes[1]];
   const size_t nB = (size_t)mB.rows * mB.R * sizeof(double);
   mB.Zold.ensure(nB); mB.V.ensure(nB);
@@ -117,6 +118,10 @@ void Engine::par2_prepare_modeA(int m, int nrho, const aoadmm_options& opt) {
   ModeInfo& mC = modes_[t.modes[2]];
   par2_xkb(b.X.d(), mB.fac.d(), d, b.T1.d(), stream_);
   par2_modeA_combine(b.T1.d(), mC.fac.d(), b.GB.d(), d, mi.tmp.d(), b.Csys.d(), stream_);
+  if (b.slab_sharded) {                               // sums over this rank's slabs -> sums over all slabs
+    allreduce(mi.tmp.d(), mi.rows * mi.R);
+    allreduce(b.Csys.d(), (int64_t)b.R * b.R);
+  }
   {
     Coef c[1] = {coef(t.weight)};                     // A{m} = w*A{m}  (:169); last_mttkrp = A/w
     const double* x[1] = {mi.tmp.d()};
@@ -173,13 +178,16 @@ void Engine::par2_update_B(int m, const aoadmm_options& opt, int iter) {
   a.Z = constr ? mi.Z.d() : nullptr; a.muZ = constr ? mi.mu.d() : nullptr;
   a.norms = b.norms.d();
   a.use_constr = constr ? 1 : 0;
+  const P2AllReduce ar = [this](double* buf, int64_t n) { allreduce(buf, n); };
+  double* psum = b.slab_sharded ? b.psum.d() : nullptr;
+  double* part4 = b.slab_sharded ? b.psum.d() + (int64_t)b.R * b.R + 8 : nullptr;
   for (int it = 0; it < opt.MaxInnerIters; ++it) {
-    par2_b_iteration(a, d, ctl, stream_);
+    par2_b_iteration(a, d, ctl, stream_, psum, ar);
     if (constr)
       par2_b_constraint(mi.prox, mi.fac.d(), mi.Z.d(), mi.mu.d(), mi.Zold.d(), mi.V.d(), b.rhok.d(), d, mi.proxws.d(),
                         b.norms.d(), ctl, stream_);
-    par2_b_finalize(b.norms.d(), b.K, constr ? 1 : 0, ctl, opt.MaxInnerIters, opt.innerRelPrTol_coupl,
-                    opt.innerRelPrTol_constr, opt.innerRelDualTol_coupl, opt.innerRelDualTol_constr, stream_);
+    par2_b_finalize(b.norms.d(), d, constr ? 1 : 0, ctl, opt.MaxInnerIters, opt.innerRelPrTol_coupl,
+                    opt.innerRelPrTol_constr, opt.innerRelDualTol_coupl, opt.innerRelDualTol_constr, stream_, part4, ar);
   }
   par2_gram(mi.fac.d(), d, b.GB.d(), stream_);                                           // :216-218
   mi.version++;
@@ -195,13 +203,26 @@ void Engine::par2_update_C(int m, const aoadmm_options& opt) {
   ModeInfo& mB = modes_[t.modes[1]];
   AdmmCtl* ctl = ctl_of_mode(m);
   par2_xkb(b.X.d(), mB.fac.d(), d, b.T1.d(), stream_);
+  const size_t RR = (size_t)b.R * b.R;
+  if (b.slab_sharded) {                               // rows of the other ranks arrive through the all-reduce
+    AO_HIP(hipMemsetAsync(b.ac.p, 0, (size_t)b.K * b.R * 8, stream_));
+    AO_HIP(hipMemsetAsync(b.rhoc.p, 0, (size_t)b.K * 8, stream_));
+    AO_HIP(hipMemsetAsync(b.Lc.p, 0, (size_t)b.K * RR * 8, stream_));
+  }
   par2_c_system(mA.fac.d(), b.T1.d(), mA.gram.d(), b.GB.d(), t.weight, has_ridge_ ? mi.ridge : 0.0,
                 opt.bsum ? opt.bsum_weight / 2 : 0.0, mi.constrained ? 1 : 0, d, mi.fac.d(), b.ac.d(), b.rhoc.d(),
-                b.rhomax.d(), b.Lc.d(), ctl, stream_);
+                b.Lc.d(), ctl, stream_);
+  if (b.slab_sharded) {
+    allreduce(b.ac.d(), (int64_t)b.K * b.R);
+    allreduce(b.rhoc.d(), b.K);
+    allreduce(b.Lc.d(), (int64_t)b.K * RR);
+  }
+  par2_rho_max(b.rhoc.d(), b.K, b.rhomax.d(), stream_);
+  const P2Dims dall = b.dims_all();                   // the K x R row systems are solved on every rank
   t.last_pos = 2;                                                                        // last_m(p) = 3
   ctl_reset(ctl, stream_);
   if (!mi.constrained) {
-    par2_c_rowsolve(b.ac.d(), b.rhoc.d(), b.Lc.d(), nullptr, nullptr, 0, d, mi.fac.d(), nullptr, stream_);   // :236
+    par2_c_rowsolve(b.ac.d(), b.rhoc.d(), b.Lc.d(), nullptr, nullptr, 0, dall, mi.fac.d(), nullptr, stream_);   // :236
   } else {
     double* sl = resid_slots(m);
     FinalizeArgs fa;
@@ -210,7 +231,7 @@ void Engine::par2_update_C(int m, const aoadmm_options& opt) {
     fa.tol_pr_constr = opt.innerRelPrTol_constr; fa.tol_du_constr = opt.innerRelDualTol_constr;
     fa.slots[0] = sl; fa.constrained[0] = 1; fa.coupled[0] = 0;
     for (int it = 0; it < opt.MaxInnerIters; ++it) {
-      par2_c_rowsolve(b.ac.d(), b.rhoc.d(), b.Lc.d(), mi.Z.d(), mi.mu.d(), 1, d, mi.fac.d(), ctl, stream_);  // :603-606
+      par2_c_rowsolve(b.ac.d(), b.rhoc.d(), b.Lc.d(), mi.Z.d(), mi.mu.d(), 1, dall, mi.fac.d(), ctl, stream_);  // :603-606
       // update_constraint with max(rho) (:1423-1424)
       constraint_update(mi.prox, mi.fac.d(), mi.Z.d(), mi.mu.d(), mi.Zold.d(), mi.V.d(), mi.rows, mi.R, b.rhomax.d(),
                         1.0, mi.proxws.d(), sl, redws_.d(), ctl, stream_);
@@ -227,10 +248,41 @@ void Engine::par2_objective_enqueue(TensorInfo& t) {
   ModeInfo& mA = modes_[t.modes[0]];
   ModeInfo& mB = modes_[t.modes[1]];
   ModeInfo& mC = modes_[t.modes[2]];
+  const bool regs = mB.constrained && prox_has_reg_value(mB.prox.type);
+  if (b.slab_sharded) {                               // per-slab values of the other ranks arrive through the all-reduce
+    AO_HIP(hipMemsetAsync(b.res.p, 0, (size_t)b.K * 8, stream_));
+    AO_HIP(hipMemsetAsync(b.q.p, 0, (size_t)b.K * 4 * 8, stream_));
+    if (regs) AO_HIP(hipMemsetAsync(b.regv.p, 0, (size_t)b.K * 8, stream_));
+  }
   par2_residual(b.X.d(), mA.fac.d(), mB.fac.d(), mC.fac.d(), d, b.res.d(), stream_);
   par2_b_gaps(mB.fac.d(), b.P.d(), b.DeltaB.d(), mB.constrained ? mB.Z.d() : nullptr, d, b.q.d(), stream_);
-  if (mB.constrained && prox_has_reg_value(mB.prox.type))
-    par2_reg_values(mB.fac.d(), mB.prox.type, mB.prox.p0, d, b.regv.d(), stream_);
+  if (regs) par2_reg_values(mB.fac.d(), mB.prox.type, mB.prox.p0, d, b.regv.d(), stream_);
+  if (b.slab_sharded) {
+    // res[K] carries the not-positive-definite flags of this block's modes, so that a Cholesky failure in one
+    // rank's slabs stops every rank (finish_eval) instead of leaving the others waiting in a collective
+    par2_collect_notpd(ctl_of_mode(t.modes[0]), ctl_of_mode(t.modes[1]), ctl_of_mode(t.modes[2]), b.res.d() + b.K, stream_);
+    allreduce(b.res.d(), b.K + 1);
+    allreduce(b.q.d(), (int64_t)b.K * 4);
+    if (regs) allreduce(b.regv.d(), b.K);
+  }
+}
+
+// End of a solve with slab-sharded blocks: every rank receives the slabs the others updated (G.fac{B}, G.P,
+// G.mu_DeltaB and, if B_k is constrained, its split and dual variables), so aoadmm_state_get returns the same
+// struct on every rank.
+void Engine::par2_gather_slabs(TensorInfo& t) {
+  Par2Block& b = t.p2;
+  if (!b.slab_sharded) return;
+  ModeInfo& mB = modes_[t.modes[1]];
+  const int64_t n = b.Jtot * b.R, e0 = b.off_h[b.k0] * b.R, e1 = b.off_h[b.k1] * b.R;
+  auto gather = [&](DevBuf& buf) {
+    if (e0 > 0) AO_HIP(hipMemsetAsync(buf.p, 0, (size_t)e0 * 8, stream_));
+    if (e1 < n) AO_HIP(hipMemsetAsync(buf.d() + e1, 0, (size_t)(n - e1) * 8, stream_));
+    allreduce(buf.d(), n);
+  };
+  gather(mB.fac); gather(b.P); gather(b.muDB);
+  if (mB.constrained && mB.has_Z) { gather(mB.Z); gather(mB.mu); }
+  mB.version++;
 }
 
 }  // namespace aoadmm

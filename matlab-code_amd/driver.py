@@ -225,6 +225,7 @@ def _make_options(alg_options):
     hip = alg_options.get('hip', {})
     o.use_dimtree = int(hip.get('use_dimtree', 1))
     o.no_permuted_copy = int(hip.get('no_permuted_copy', 0))
+    o.par2_slab_sharding = int(hip.get('par2_slab_sharding', 0))
     return o
 
 

@@ -324,6 +324,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   o.use_dimtree = 1;
   if (const mxArray* hip = field(opt, "hip", false))
     if (const mxArray* f = field(hip, "no_permuted_copy", false)) o.no_permuted_copy = (int)mxGetScalar(f);
+    if (const mxArray* f = field(hip, "par2_slab_sharding", false)) o.par2_slab_sharding = (int)mxGetScalar(f);
 
   // ---- solve
   const int n = o.MaxOuterIters + 1;

@@ -99,3 +99,87 @@ def test_sharded_four_way(pkg):
     rng = np.random.default_rng(91)
     Z, io, _ = cp_model((12, 9, 8, 7), 3, rng, [('non-negativity',), None, ('l2-ball', 1.0), ('non-negativity',)])
     compare(*run_sharded(pkg, Z, io, options(MaxOuterIters=6), 2))
+
+
+# ---- PARAFAC2 slabs sharded over the ranks (aoadmm_options.par2_slab_sharding = 1) ---------------------------------
+def run_sharded_par2(pkg, Z, io, opt, world, seed=7):
+    opt = dict(opt)
+    opt['hip'] = dict(par2_slab_sharding=1)
+    rng = np.random.default_rng(seed)
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=rng)
+    oopt = {k: v for k, v in opt.items() if k != 'hip'}
+    _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=oopt, init=copy.deepcopy(G))
+    key = next(_keys)
+    res, err = [None] * world, [None] * world
+
+    def rank_main(r):
+        try:
+            with pkg.Engine(0) as e:
+                e.comm_init_local(key, r, world)
+                _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=e)
+                res[r] = (Fg, og)
+        except BaseException as ex:   # noqa: BLE001
+            err[r] = ex
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for r, ex in enumerate(err):
+        assert ex is None, 'rank %d: %r' % (r, ex)
+
+    def same(a, b, what):
+        if a is None:
+            return
+        if isinstance(a, (list, tuple)):
+            for x, y in zip(a, b):
+                same(x, y, what)
+        elif isinstance(a, dict):
+            for k in a:
+                same(a[k], b[k], what)
+        else:
+            assert np.array_equal(a, b), what
+    for r in range(1, world):       # after the final gather every rank returns the same struct, bit for bit
+        for key_ in ('fac', 'constraint_fac', 'constraint_dual_fac', 'DeltaB', 'P', 'mu_DeltaB'):
+            same(res[0][0][key_], res[r][0][key_], (key_, r))
+        assert np.array_equal(res[0][1]['func_val_conv'], res[r][1]['func_val_conv'])
+    return Fo, oo, res[0][0], res[0][1]
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_slab_sharded_irregular_parafac2(pkg, world):
+    """config 4 family, K = 13 ragged slabs over 2 (7+6) or 3 (5+5+3) ranks: per-slab kernels on the own range,
+    all-reduced sums for mode A, DeltaB, the residual means and the objective, gathered C-mode row systems."""
+    from helpers import script4_model
+    rng = np.random.default_rng(10)
+    Z, io = script4_model(rng, K=13)
+    compare_par2(*run_sharded_par2(pkg, Z, io, options(MaxOuterIters=10), world))
+
+
+def test_slab_sharded_constrained_and_regularised_Bk(pkg):
+    from helpers import script4_model
+    rng = np.random.default_rng(11)
+    Z, io = script4_model(rng, K=6, constraints_B=('unimodality', False))
+    opt = options(MaxOuterIters=8, iter_start_PAR2Bkconstraint=3, increase_factor_rhoBk=2.0)
+    compare_par2(*run_sharded_par2(pkg, Z, io, opt, 2))
+    Z, io = script4_model(rng, K=7, constraints_B=('l1 regularization', 0.01))
+    compare_par2(*run_sharded_par2(pkg, Z, io, options(MaxOuterIters=6), 2))
+
+
+def test_slab_sharded_parafac2_coupled_to_row_sharded_cp(pkg):
+    """config 1: CP block row-sharded along mode 1 and PARAFAC2 block slab-sharded, first modes exactly coupled."""
+    rng = np.random.default_rng(12)
+    Z, io = script1_model(rng, dims=(20, 30, 40))
+    compare_par2(*run_sharded_par2(pkg, Z, io, options(MaxOuterIters=6), 2))
+
+
+def test_slab_sharding_with_early_inner_exit(pkg):
+    """Non-zero inner tolerances: the device-side loop control must stay in step on all ranks (same all-reduced
+    residual means), with the collectives still issued after the loop went inactive."""
+    from helpers import script4_model
+    rng = np.random.default_rng(13)
+    Z, io = script4_model(rng, K=9)
+    opt = options(MaxOuterIters=15, MaxInnerIters=8, innerRelPrTol_coupl=1e-2, innerRelDualTol_coupl=1e-2,
+                  innerRelPrTol_constr=1e-2, innerRelDualTol_constr=1e-2)
+    compare_par2(*run_sharded_par2(pkg, Z, io, opt, 2))
