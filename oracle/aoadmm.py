@@ -279,9 +279,18 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
                 D = G['coupling_fac'][cid]
                 muD = G['coupling_dual_fac'][mm]
                 H = ctm[mm]
-                if is_par2_C(mm):
+                if is_par2_C(mm) and ctype == 1:                                   # :710-724
+                    # one (K*R) x (K*R) system for vec(C') with the common rhoC = mean(rho) (:712)
+                    rhoC = float(np.mean(rho[mm]))
+                    A_large = np.concatenate([np.ravel(A[mm][kk]) for kk in range(_K_of(Z, pp))])       # :714-716
+                    A_inner = A_large + rhoC / 2 * np.ravel(H.T @ (D - muD))       # HcI'*vec((D-mu)') = vec((H'(D-mu))')  (:717)
+                    if constrained[mm]:
+                        A_inner = A_inner + rhoC / 2 * np.ravel(G['constraint_fac'][mm] - G['constraint_dual_fac'][mm])   # :719
+                    x = sla.cho_solve((L[mm], True), A_inner)                        # :721
+                    G['fac'][mm] = x.reshape(G['fac'][mm].shape)                     # :722 (vec of C' = rows of C back to back)
+                elif is_par2_C(mm):
                     if ctype not in (0, 2, 3, 4):
-                        raise NotImplementedError('PAR2 C-mode coupling types 1/5 (kron system) not restated')
+                        raise NotImplementedError('PAR2 C-mode coupling type 5 (kron system) not restated')
                     for kk in range(_K_of(Z, pp)):
                         r2 = rho[mm][kk] / 2
                         if ctype == 0:                                             # :640
@@ -719,9 +728,18 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
                 ctype = int(Z['coupling']['coupling_type'][coupl_id - 1])
                 for m in coupled_modes:
                     R_ = None
-                    if is_par2_C(m):
-                        if ctype in (1, 5):
-                            raise NotImplementedError('PAR2 C-mode coupling types 1/5 not restated')
+                    if is_par2_C(m) and ctype == 1:                            # :282-297
+                        Kc = _K_of(Z, which_p[m])
+                        R_ = B[m][0].shape[0]
+                        HcI = np.kron(ctm[m], np.eye(R_))                                          # :283
+                        B2[m] = float(np.mean(rho[m])) / 2 * (HcI.T @ HcI)                          # :284
+                        B2[m] = sla.block_diag(*[B[m][k] for k in range(Kc)]) + B2[m]               # :286
+                        if constrained[m]:
+                            B2[m] = B2[m] + float(np.mean(rho[m])) / 2 * np.eye(B2[m].shape[0])    # :292
+                        L[m] = np.linalg.cholesky(B2[m])                                           # :296
+                    elif is_par2_C(m):
+                        if ctype == 5:
+                            raise NotImplementedError('PAR2 C-mode coupling type 5 not restated')
                         for k in range(_K_of(Z, which_p[m])):
                             R_ = B[m][k].shape[0]
                             if ctype == 2:

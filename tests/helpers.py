@@ -201,3 +201,44 @@ def transformed_coupling_model(rng, ctype, noise=0.05):
     distr = [lambda a, b: rng.random((a, b))] * 6
     io = dict(lambdas_init=[[1] * R1, [1] * R4], nvecs=0, distr=distr, normalize=1)
     return Z, io
+
+
+def par2_C_coupled_model(rng, ctype, noise=0.0, K=16, I2=12, Jk=14):
+    """example_script14_CP_PAR2_couplC_doublesamplingrate.m:20-44 scaled down: a CP tensor whose first mode is coupled
+    to the C mode (third mode) of a PARAFAC2 block.  ctype 1: H{1}*C1 = Delta = H{6}*C6 with H{6} taking every second
+    of the K rows (script 14); ctype 0: C1 = C6 exactly (K rows each)."""
+    R = 3
+    C6 = rng.random((K, R)) + 0.1
+    if ctype == 1:
+        n1 = K // 2
+        sub = np.zeros((n1, K))
+        sub[np.arange(n1), 2 * np.arange(n1)] = 1.0
+        C1 = sub @ C6
+        H = [np.eye(n1), None, None, None, None, sub]
+    else:
+        n1 = K
+        C1 = C6.copy()
+        H = [None] * 6
+    X1 = full_ktensor([C1, rng.random((15, R)), rng.random((13, R))])
+    A4 = rng.random((I2, R))
+    DB = rng.standard_normal((R, R))
+    Xk = []
+    for k in range(K):
+        Q, _ = np.linalg.qr(rng.standard_normal((Jk, R)))
+        Xk.append(A4 @ np.diag(C6[k]) @ (Q @ DB).T)
+    if noise > 0:
+        N = rng.standard_normal(X1.shape)
+        X1 = X1 + noise * np.linalg.norm(X1) / np.linalg.norm(N) * N
+        Xk = [x + noise * np.linalg.norm(x) / np.sqrt(x.size) * rng.standard_normal(x.shape) for x in Xk]
+    X1 /= np.linalg.norm(X1)
+    nrm = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in Xk))
+    Xk = [x / nrm for x in Xk]
+    Z = dict(loss_function=['Frobenius'] * 2, model=['CP', 'PAR2'], modes=[[1, 2, 3], [4, 5, 6]],
+             size=[n1, 15, 13, I2, [Jk] * K, K],
+             coupling=dict(lin_coupled_modes=[1, 0, 0, 0, 0, 1], coupling_type=[ctype], coupl_trafo_matrices=H),
+             constrained_modes=[1, 1, 1, 1, 0, 1],
+             constraints=[('non-negativity',)] * 4 + [None, ('non-negativity',)], weights=[0.5, 0.5], object=[X1, Xk])
+    distr = [lambda a, b: rng.random((a, b)) + 0.1] + [lambda a, b: rng.random((a, b))] * 3 + \
+            [lambda a, b: rng.standard_normal((a, b)), lambda a, b: rng.random((a, b)) + 0.1]
+    io = dict(lambdas_init=[[1] * R, [1] * R], nvecs=0, distr=distr, normalize=1)
+    return Z, io
