@@ -60,11 +60,16 @@ void par2_b_finalize(const double* norms, const P2Dims& d, int use_constr, AdmmC
                      double* part4, const P2AllReduce& allreduce);
 
 // mode C: a(k,r) = w * sum_i A(i,r) T1[k](i,r) ; C_k = GA .* GB[k] ; rho_k ; B_k (+rho_k/2 I if constrained) ; chol  (:221-240)
+// nrho = how many rho_k/2*I terms the system gets (constraint, exact coupling :262-264); raw = 1: L receives B_k itself
 void par2_c_system(const double* A, const double* T1, const double* GA, const double* GB, double w, double ridge,
-                   double bsum_half, int constrained, const P2Dims& d, const double* Cfac, double* a, double* rho,
+                   double bsum_half, int nrho, int raw, const P2Dims& d, const double* Cfac, double* a, double* rho,
                    double* L, AdmmCtl* ctl, hipStream_t s);
 // rhomax = max_k rho_k (:1424); separate because a slab-sharded block gathers rho first
-void par2_rho_max(const double* rho, int K, double* rhomax, hipStream_t s);
+void par2_rho_max(const double* rho, int K, double* rhomax, hipStream_t s, double* rhomean = nullptr,
+                  double* rhosum = nullptr);
+// (K*R) x (K*R) system of a C mode coupled through H*C = Delta (:283-293); HtH = H'*H (K x K), rhoC = mean(rho) on the device
+void par2_c_big_system(const double* Bk, const double* HtH, const double* rhoC, int constrained, int K, int R, double* M,
+                       hipStream_t s);
 // row k: rhs = a_k (+ rho_k/2 (Z(k,:) - mu(k,:))) ; C(k,:) = L_k'\(L_k\rhs)      (:236, :604-605)
 void par2_c_rowsolve(const double* a, const double* rho, const double* L, const double* Z, const double* mu,
                      int use_admm, const P2Dims& d, double* Cfac, const AdmmCtl* ctl, hipStream_t s);

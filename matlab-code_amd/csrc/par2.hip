@@ -524,7 +524,7 @@ void par2_b_finalize(const double* norms, const P2Dims& d, int use_constr, AdmmC
 // C mode
 // ---------------------------------------------------------------------------
 __global__ void par2_c_system_k(const double* A, const double* T1, const double* GA, const double* GB, double w,
-                                double ridge, double bsum_half, int constrained, P2Dims d, const double* Cfac,
+                                double ridge, double bsum_half, int nrho, int raw, P2Dims d, const double* Cfac,
                                 double* a, double* rho, double* L, AdmmCtl* ctl) {
   extern __shared__ double sh[];
   __shared__ double rk;
@@ -545,31 +545,63 @@ __global__ void par2_c_system_k(const double* A, const double* T1, const double*
   __syncthreads();
   for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
     double b = w * sh[e];
-    if (e % R == e / R) b += ridge + bsum_half + (constrained ? rk / 2 : 0.0);   // :224-239
+    if (e % R == e / R) b += ridge + bsum_half + nrho * (rk / 2);   // :224-239 ; coupled: :262-264
     sh[e] = b;
   }
   __syncthreads();
+  if (raw) {                                         // the (K*R)-system of coupling type 1 wants B_k itself (:286)
+    for (int e = threadIdx.x; e < R * R; e += blockDim.x) L[(int64_t)k * R * R + e] = sh[e];
+    return;
+  }
   const bool ok = chol_lds(sh, R);
   if (ok)
     for (int e = threadIdx.x; e < R * R; e += blockDim.x) L[(int64_t)k * R * R + e] = sh[e];
   else if (threadIdx.x == 0 && ctl) ctl->notpd = 1;
 }
-__global__ void par2_max_k(const double* x, int n, double* out) {
+__global__ void par2_max_k(const double* x, int n, double* out, double* mean, double* sum) {
   if (threadIdx.x == 0) {
-    double m = x[0];
-    for (int i = 1; i < n; ++i) m = fmax(m, x[i]);
+    double m = x[0], t = x[0];
+    for (int i = 1; i < n; ++i) { m = fmax(m, x[i]); t += x[i]; }
     out[0] = m;                                                        // max(rho)  (:1424)
+    if (sum) sum[0] = t;                                               // sum(rho)  (:736)
+    if (mean) mean[0] = t / n;                                         // mean(rho) (:284, :712)
   }
 }
 void par2_c_system(const double* A, const double* T1, const double* GA, const double* GB, double w, double ridge,
-                   double bsum_half, int constrained, const P2Dims& d, const double* Cfac, double* a, double* rho,
+                   double bsum_half, int nrho, int raw, const P2Dims& d, const double* Cfac, double* a, double* rho,
                    double* L, AdmmCtl* ctl, hipStream_t s) {
   par2_c_system_k<<<d.k1 - d.k0, kP2Threads, (size_t)d.R * d.R * sizeof(double), s>>>(A, T1, GA, GB, w, ridge, bsum_half,
-                                                                            constrained, d, Cfac, a, rho, L, ctl);
+                                                                            nrho, raw, d, Cfac, a, rho, L, ctl);
   AO_KERNEL_CHECK();
 }
-void par2_rho_max(const double* rho, int K, double* rhomax, hipStream_t s) {
-  par2_max_k<<<1, 64, 0, s>>>(rho, K, rhomax);
+void par2_rho_max(const double* rho, int K, double* rhomax, hipStream_t s, double* rhomean, double* rhosum) {
+  par2_max_k<<<1, 64, 0, s>>>(rho, K, rhomax, rhomean, rhosum);
+  AO_KERNEL_CHECK();
+}
+
+// M = blkdiag(B_1..B_K) + rhoC/2 * kron(H'H, I_R) (+ rhoC/2 * I if the mode is constrained), unknowns ordered as the
+// rows of C back to back: index k*R + r   (cmtf_fun_AOADMM.m:283-293)
+__global__ void par2_c_big_system_k(const double* Bk, const double* HtH, const double* rhoC, int constrained, int K,
+                                    int R, double* M) {
+  const int n = K * R;
+  const double h = rhoC[0] / 2;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)n * n;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int u = (int)(e % n), v = (int)(e / n);
+    const int k = u / R, r = u % R, k2 = v / R, q = v % R;
+    double m = 0.0;
+    if (k == k2) m = Bk[(int64_t)k * R * R + r + R * q];
+    if (r == q) m += h * HtH[k + (int64_t)K * k2];
+    if (constrained && u == v) m += h;
+    M[e] = m;
+  }
+}
+void par2_c_big_system(const double* Bk, const double* HtH, const double* rhoC, int constrained, int K, int R, double* M,
+                       hipStream_t s) {
+  const int64_t n2 = (int64_t)K * R * K * R;
+  int64_t nb = cdiv(n2, 256);
+  if (nb > 2048) nb = 2048;
+  par2_c_big_system_k<<<(unsigned)nb, 256, 0, s>>>(Bk, HtH, rhoC, constrained, K, R, M);
   AO_KERNEL_CHECK();
 }
 
@@ -583,7 +615,7 @@ __global__ void par2_c_rowsolve_k(const double* a, const double* rho, const doub
   double x[kMaxRank];
   for (int r = 0; r < R; ++r) {
     double v = a[k + K * r];
-    if (use_admm) v += rho[k] / 2 * (Z[k + K * r] - mu[k + K * r]);             // :604
+    if (use_admm) v += rho[k] / 2 * (Z[k + K * r] - (mu ? mu[k + K * r] : 0.0));   // :604 ; coupled: Z holds the whole bracket (:640-643)
     x[r] = v;
   }
   for (int r = 0; r < R; ++r) {

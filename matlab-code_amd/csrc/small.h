@@ -100,6 +100,13 @@ void chol_only(double* L, const double* B, int R, AdmmCtl* ctl, hipStream_t s);
 void sym_eig_small(const double* B, int n, double* w, double* V, hipStream_t s);
 // BB <- AA \ BB, AA symmetric positive definite q x q (destroyed), BB q x nrhs; failure -> ctl->notpd
 void spd_solve_left(double* AA, int64_t q, double* BB, int nrhs, AdmmCtl* ctl, hipStream_t s);
+// Dense SPD system of order n <= kDenseMaxN: M (n x n, column-major) is overwritten by its Cholesky factor, Minv
+// receives inv(M); ctl->notpd is raised if a pivot is not positive.  dense_symv_rows applies Minv to the rows of a
+// K x R matrix taken back to back (n = K*R).
+constexpr int kDenseMaxN = 2048;
+void dense_spd_inverse(double* M, double* Minv, int n, AdmmCtl* ctl, hipStream_t s);
+void dense_symv_rows(const double* Minv, const double* rhs, double* out, int K, int R, const AdmmCtl* ctl,
+                     hipStream_t s);
 // W(i,j) /= rho/2*(lam_mul*lam[i] + shift_mul) + mu[j]
 void sylv_scale(double* W, int64_t rows, int R, const double* lam, const double* mu, const double* rho, double lam_mul,
                 double shift_mul, const AdmmCtl* ctl, hipStream_t s);

@@ -526,6 +526,95 @@ void chol_only(double* L, const double* B, int R, AdmmCtl* ctl, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
+// Dense SPD systems of a few hundred unknowns (the (K*R) x (K*R) system of a PARAFAC2 C mode coupled through a
+// transformation matrix, cmtf_fun_AOADMM.m:282-297): Cholesky in global memory by one workgroup (right-looking,
+// column by column), then the explicit inverse, one workgroup per column of the identity, so that every inner
+// iteration is a single matrix-vector product instead of 2n dependent substitution steps.
+constexpr int kDenseThreads = 1024;
+__global__ __launch_bounds__(kDenseThreads) void dense_chol_k(double* M, int n, AdmmCtl* ctl) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    double* cj = M + (int64_t)n * j;
+    if (threadIdx.x == 0) {
+      const double d = cj[j];
+      if (!(d > 0.0)) bad = 1;
+      cj[j] = sqrt(d);
+    }
+    __syncthreads();
+    if (bad) break;
+    const double piv = cj[j];
+    __syncthreads();                                 // every thread has read the pivot before the column is scaled
+    for (int i = j + 1 + threadIdx.x; i < n; i += kDenseThreads) cj[i] /= piv;
+    __syncthreads();
+    // trailing update of the lower triangle: M(i,c) -= L(i,j) * L(c,j), c = j+1..n-1, i = c..n-1
+    const int m = n - j - 1;
+    for (int64_t e = threadIdx.x; e < (int64_t)m * m; e += kDenseThreads) {
+      const int c = j + 1 + (int)(e / m), i = j + 1 + (int)(e % m);
+      if (i >= c) M[i + (int64_t)n * c] -= cj[i] * cj[c];
+    }
+    __syncthreads();
+  }
+  if (bad && threadIdx.x == 0 && ctl) ctl->notpd = 1;
+}
+// column `blockIdx.x` of inv(L*L'): forward and backward substitution of a unit vector, x in LDS
+__global__ __launch_bounds__(256) void dense_inverse_k(const double* L, int n, double* Minv) {
+  extern __shared__ double x[];
+  const int col = blockIdx.x;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) x[i] = (i == col) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int j = col; j < n; ++j) {                    // L y = e_col  (y_j = 0 for j < col)
+    const double* cj = L + (int64_t)n * j;
+    if (threadIdx.x == 0) x[j] /= cj[j];
+    __syncthreads();
+    const double xj = x[j];
+    for (int i = j + 1 + threadIdx.x; i < n; i += blockDim.x) x[i] -= cj[i] * xj;
+    __syncthreads();
+  }
+  for (int j = n - 1; j >= 0; --j) {                 // L' x = y
+    const double* cj = L + (int64_t)n * j;
+    double acc = 0.0;
+    for (int i = j + 1 + threadIdx.x; i < n; i += blockDim.x) acc += cj[i] * x[i];
+    // fixed-order block sum (blockDim is a power of two)
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = blockDim.x >> 1; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) x[j] = (x[j] - red[0]) / cj[j];
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) Minv[i + (int64_t)n * col] = x[i];
+}
+void dense_spd_inverse(double* M, double* Minv, int n, AdmmCtl* ctl, hipStream_t s) {
+  AO_REQUIRE(n > 0 && n <= kDenseMaxN, "dense system of order %d (limit %d)", n, kDenseMaxN);
+  dense_chol_k<<<1, kDenseThreads, 0, s>>>(M, n, ctl);
+  AO_KERNEL_CHECK();
+  dense_inverse_k<<<n, 256, (size_t)n * sizeof(double), s>>>(M, n, Minv);
+  AO_KERNEL_CHECK();
+}
+// out(k,r) = sum_{k',q} Minv[(k*R+r), (k'*R+q)] * rhs(k',q): the unknowns are the rows of the K x R matrix back to
+// back (vec(C'), cmtf_fun_AOADMM.m:717-722); rhs and out are column-major K x R.  One wave per unknown.
+__global__ __launch_bounds__(64) void dense_symv_rows_k(const double* Minv, const double* rhs, double* out, int K, int R,
+                                                        const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  const int n = K * R, u = blockIdx.x, k = u / R, r = u % R;
+  const double* row = Minv + (int64_t)n * u;         // symmetric: column u = row u, contiguous
+  double acc = 0.0;
+  for (int v = threadIdx.x; v < n; v += 64) acc += row[v] * rhs[(v / R) + K * (v % R)];
+  for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if (threadIdx.x == 0) out[k + K * r] = acc;
+}
+void dense_symv_rows(const double* Minv, const double* rhs, double* out, int K, int R, const AdmmCtl* ctl,
+                     hipStream_t s) {
+  dense_symv_rows_k<<<K * R, 64, 0, s>>>(Minv, rhs, out, K, R, ctl);
+  AO_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
 // Symmetric eigendecomposition of a small matrix (n <= 64) by cyclic Jacobi, one wave, matrix and
 // eigenvectors in LDS: B = V diag(w) V'.  Used by the Sylvester-type primal updates of the transformed
 // couplings (cmtf_fun_AOADMM.m:707, :1016), where B is the R x R system matrix of one mode.

@@ -99,6 +99,9 @@ struct Par2Block {
   bool slab_sharded = false;
   int k0 = 0, k1 = 0;
   DevBuf psum;                    // R*R+1 partial sums of DeltaB, then 4 residual means
+  // coupled C mode: sum(rho_k); H'H, the (K*R)^2 system and its inverse for coupling type 1 (:282-297)
+  DevBuf rhosum, HtH, Mbig, Minv;
+  bool have_HtH = false;
   P2Dims dims() const {
     P2Dims d;
     d.K = K; d.I = I; d.R = R; d.off = off_d.as<int64_t>(); d.off_h = off_h.data(); d.Jtot = Jtot; d.Jmax = Jmax;
@@ -220,6 +223,7 @@ class Engine {
   void par2_prepare_modeA(int m, int nrho, const aoadmm_options& opt);
   void par2_update_B(int m, const aoadmm_options& opt, int iter);
   void par2_update_C(int m, const aoadmm_options& opt);
+  void par2_prepare_C_coupled(int m, int ctype, const aoadmm_options& opt);
   void par2_objective_enqueue(TensorInfo& t);
   double* resid_slots(int m);
   std::vector<int> update_sequence(int p) const;

@@ -277,8 +277,6 @@ void Engine::model_end() {
       // check_data_input.m:33-35
       AO_REQUIRE(mi.coupling < 0, "Coupling in 2. mode (the varying mode) of Parafac2 decomposition not supported.");
     }
-    if (mi.pos == 2 && mi.coupling >= 0)
-      throw Error(AOADMM_ERR_UNSUPPORTED, "coupling of the PARAFAC2 C mode is not in the device path yet (use the MATLAB path)");
   }
   for (int c = 0; c < n_couplings_; ++c) {
     CouplingInfo& ci = couplings_[c];
@@ -288,6 +286,9 @@ void Engine::model_end() {
       if (modes_[m].coupling == c) ci.modes.push_back(m);
     AO_REQUIRE(!ci.modes.empty(), "coupling %d couples no mode", c);
     AO_REQUIRE(ci.modes.size() <= 8, "more than 8 modes in one coupling");
+    for (int m : ci.modes)
+      if (tensors_[modes_[m].tensor].par2 && modes_[m].pos == 2 && ci.type != 0 && ci.type != 1)
+        throw Error(AOADMM_ERR_UNSUPPORTED, fmt("coupling type %d of a PARAFAC2 C mode is not in the device path (types 0 and 1 are; use the MATLAB path)", ci.type));
     const ModeInfo& m0 = modes_[ci.modes[0]];
     auto need_H = [&](int m) { AO_REQUIRE(modes_[m].hr > 0, "Coupling matrix for mode %d is missing.", m + 1); };
     switch (ci.type) {
@@ -1175,6 +1176,24 @@ __global__ void coupling_coefs_k(double* coef, const double* const* rhos, int n)
   }
 }
 
+// Delta(k,:) = sum_j rho_j(k) * (C_j + mu_j)(k,:) / sum_j rho_j(k)   (:661-675): rho_j is a K-vector for a PARAFAC2
+// C mode (vec[j] = 1) and a scalar otherwise
+struct RowMeanArgs { const double* fac[8]; const double* mu[8]; const double* rho[8]; int vec[8]; int n; int64_t rows; int cols; };
+__global__ void coupling_rowmean_k(double* Delta, RowMeanArgs a, const AdmmCtl* ctl) {
+  if (ctl != nullptr && ctl->active == 0) return;
+  const int64_t tot = a.rows * a.cols;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = e % a.rows;
+    double acc = 0.0, sr = 0.0;
+    for (int j = 0; j < a.n; ++j) {
+      const double rj = a.vec[j] ? a.rho[j][k] : a.rho[j][0];
+      acc += rj * (a.fac[j][e] + a.mu[j][e]);
+      sr += rj;
+    }
+    Delta[e] = 1.0 / sr * acc;
+  }
+}
+
 struct AAArgs { const double* H[8]; const double* rho[8]; int R[8]; int n; int Rc; };
 __global__ void coupling_AA_k(double* AA, AAArgs a) {
   // AA = sum_j rho_j * H_j * H_j'   (:941-954 ; :1033-1047 with H2 and the common rhoC)
@@ -1211,7 +1230,16 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
   ctl_reset(ctl, stream_);
   // per-outer-iteration constants
   std::vector<const double*> hp(n);
-  for (int j = 0; j < n; ++j) hp[j] = modes_[ci.modes[j]].rho.d();
+  bool any_pc = false;                                // a PARAFAC2 C mode in this coupling (types 0 and 1 only)
+  auto pc_block = [&](const ModeInfo& mi) -> Par2Block* {
+    return (tensors_[mi.tensor].par2 && mi.pos == 2) ? &tensors_[mi.tensor].p2 : nullptr;
+  };
+  for (int j = 0; j < n; ++j) {
+    const ModeInfo& mj = modes_[ci.modes[j]];
+    Par2Block* pb = pc_block(mj);
+    hp[j] = pb ? pb->rhosum.d() : mj.rho.d();         // type 1 weighs a C mode with sum(rho) (:736)
+    any_pc = any_pc || pb != nullptr;
+  }
   DevBuf& rho_ptrs = ci.rho_ptrs;                     // pointers never change once the work buffers exist
   if (ci.rho_ptrs_host != hp) {
     rho_ptrs.ensure(8 * sizeof(double*));
@@ -1242,6 +1270,15 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
       ModeInfo& mi = modes_[ci.modes[j]];
       const int64_t nm = mi.rows * mi.R, ni = mi.img_rows * mi.img_cols;
       image_d(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_);
+      Par2Block* pb = pc_block(mi);
+      if (pb && ty == 0) {
+        // row k: A_inner = a_k + rho_k/2*(Delta - mu_Delta)(k,:) [+ rho_k/2*(Z - mu)(k,:)], solved with L_k (:638-645)
+        Coef cf[4] = {coef(1.0), coef(-1.0), coef(1.0), coef(-1.0)};
+        const double* x[4] = {mi.TD.d(), mi.muD.d(), mi.Z.d(), mi.mu.d()};
+        ew_lincomb(mi.RHS.d(), nm, mi.constrained ? 4 : 2, cf, x, ctl, stream_);
+        par2_c_rowsolve(pb->ac.d(), pb->rhoc.d(), pb->Lc.d(), mi.RHS.d(), nullptr, 1, pb->dims_all(), mi.fac.d(), ctl, stream_);
+        continue;
+      }
       if (ty == 0 || ty == 3 || ty == 4) {
         Coef cf[5] = {coef(1.0), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), -0.5), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), -0.5)};
         const double* x[5] = {mi.Aeff, mi.TD.d(), mi.muD.d(), mi.Z.d(), mi.mu.d()};
@@ -1255,7 +1292,10 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
         const double* x[4] = {mi.Aeff, adj, mi.Z.d(), mi.mu.d()};
         ew_lincomb(mi.RHS.d(), nm, mi.constrained ? 4 : 2, cf, x, ctl, stream_);
       }
-      if (ty == 1 || ty == 5) {
+      if (pb && ty == 1) {
+        // vec(C') = (blkdiag(B_k) + rhoC/2*kron(H'H,I) [+ rhoC/2*I]) \ vec(A_inner') (:714-722); mi.rho holds rhoC
+        dense_symv_rows(pb->Minv.d(), mi.RHS.d(), mi.fac.d(), pb->K, pb->R, ctl, stream_);
+      } else if (ty == 1 || ty == 5) {
         // sylvester(B2, B, A_inner) (:707, :1016) with B2 = rho/2*H'H (+ rho/2*I if constrained) = U (..) U',
         // B = V diag(mu) V':  X = U * ((U' A_inner V) ./ (beta_i + mu_j)) * V'
         gemm_small(mi.W1.d(), mi.rows, mi.eUt.d(), mi.rows, mi.RHS.d(), mi.rows, mi.rows, (int)mi.rows, mi.R, 0, coef(1.0), 0.0, ctl, stream_);
@@ -1273,7 +1313,21 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
       const double* x1[1] = {ci.Delta.d()};
       ew_lincomb(ci.DeltaOld.d(), nD, 1, c1, x1, ctl, stream_);
     }
-    if (ty == 0 || ty == 1 || ty == 2) {              // weighted mean of Tf(C_j) + mu_j (:661-675, :735-741, :805-811)
+    if (ty == 0 && any_pc) {                          // per-row weights rho_j(k) (:666-675)
+      RowMeanArgs ra;
+      ra.n = n; ra.rows = ci.rows; ra.cols = (int)ci.cols;
+      for (int j = 0; j < n; ++j) {
+        ModeInfo& mi = modes_[ci.modes[j]];
+        Par2Block* pb = pc_block(mi);
+        ra.fac[j] = mi.fac.d(); ra.mu[j] = mi.muD.d();
+        ra.rho[j] = pb ? pb->rhoc.d() : mi.rho.d();
+        ra.vec[j] = pb ? 1 : 0;
+      }
+      int64_t nb = cdiv(nD, 256);
+      if (nb > 1024) nb = 1024;
+      coupling_rowmean_k<<<(unsigned)nb, 256, 0, stream_>>>(ci.Delta.d(), ra, ctl);
+      AO_KERNEL_CHECK();
+    } else if (ty == 0 || ty == 1 || ty == 2) {       // weighted mean of Tf(C_j) + mu_j (:661-675, :735-741, :805-811)
       for (int j = 0; j < n; ++j) {
         ModeInfo& mi = modes_[ci.modes[j]];
         const double* tf = image_f(mi.TF.d(), ci, mi.fac.d(), mi, ctl, stream_);
@@ -1340,10 +1394,11 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
       Coef cf[3] = {coef(1.0), coef(1.0), coef(-1.0)};
       const double* x[3] = {mi.muD.d(), tf, mi.TD.d()};
       ew_lincomb(mi.muD.d(), ni, 3, cf, x, ctl, stream_);                      // mu_Delta += Tf(C) - Sd(Delta)
-      if (mi.constrained)
+      if (mi.constrained) {
+        Par2Block* pb = pc_block(mi);                 // a C mode's prox gets max(rho) (:1423-1424)
         constraint_update(mi.prox, mi.fac.d(), mi.Z.d(), mi.mu.d(), mi.Zold.d(), mi.V.d(), mi.rows, mi.R,
-                          mi.rho.d(), 1.0, mi.proxws.d(), sl, redws_.d(), ctl, stream_);
-      else
+                          pb ? pb->rhomax.d() : mi.rho.d(), 1.0, mi.proxws.d(), sl, redws_.d(), ctl, stream_);
+      } else
         sumsq_diff(sl + 1, mi.fac.d(), nullptr, nm, redws_.d(), ctl, stream_);
       sumsq_diff(sl + 4, tf, mi.TD.d(), ni, redws_.d(), ctl, stream_);
       sumsq_diff(sl + 5, mi.muD.d(), nullptr, ni, redws_.d(), ctl, stream_);
@@ -1497,7 +1552,8 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     {
       // slabs over the ranks or every slab on every rank (aoadmm_options.par2_slab_sharding)
       const ModeInfo& mB = modes_[t.modes[1]];
-      const bool can = sharded() && world_ > 1 && !b.has_mask && !(mB.constrained && mB.prox.type == AOADMM_C_TPARAFAC2);
+      const bool can = sharded() && world_ > 1 && !b.has_mask && !(mB.constrained && mB.prox.type == AOADMM_C_TPARAFAC2) &&
+                       modes_[t.modes[2]].coupling < 0;     // a coupled C mode needs every row system on every rank
       const bool want = opt.par2_slab_sharding > 0 || (opt.par2_slab_sharding == 0 && b.K / world_ >= 1024);
       b.slab_sharded = can && want;
       const int per = (int)cdiv(b.K, world_);
@@ -1646,7 +1702,8 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
           if (modes_[m].tensor == p) {
             const bool par2 = tensors_[p].par2;
             if (par2 && modes_[m].pos == 1) par2_update_B(m, opt, iter);             // :191-218
-            else if (par2 && modes_[m].pos == 2) par2_update_C(m, opt);              // :219-248
+            else if (par2 && modes_[m].pos == 2 && cid < 0) par2_update_C(m, opt);   // :219-248
+            else if (par2 && modes_[m].pos == 2) par2_prepare_C_coupled(m, couplings_[cid].type, opt);
             else if (cid < 0) update_uncoupled_cp_mode(m, opt);
             else {
               // system of a coupled mode: +rho/2*I (types 0, 3, 4: :269, :336, :358), +rho/2*H*H' (type 2, :314),

@@ -210,7 +210,7 @@ void Engine::par2_update_C(int m, const aoadmm_options& opt) {
     AO_HIP(hipMemsetAsync(b.Lc.p, 0, (size_t)b.K * RR * 8, stream_));
   }
   par2_c_system(mA.fac.d(), b.T1.d(), mA.gram.d(), b.GB.d(), t.weight, has_ridge_ ? mi.ridge : 0.0,
-                opt.bsum ? opt.bsum_weight / 2 : 0.0, mi.constrained ? 1 : 0, d, mi.fac.d(), b.ac.d(), b.rhoc.d(),
+                opt.bsum ? opt.bsum_weight / 2 : 0.0, mi.constrained ? 1 : 0, 0, d, mi.fac.d(), b.ac.d(), b.rhoc.d(),
                 b.Lc.d(), ctl, stream_);
   if (b.slab_sharded) {
     allreduce(b.ac.d(), (int64_t)b.K * b.R);
@@ -239,6 +239,43 @@ void Engine::par2_update_C(int m, const aoadmm_options& opt) {
     }
   }
   mi.version++;
+}
+
+// mode C inside a coupling (:253-297): right-hand sides a_k, rho_k and the systems the coupled ADMM needs --
+// type 0: per-row Cholesky factors of w*C_k + rho_k/2*I (+ rho_k/2*I if constrained) (:260-267);
+// type 1: the (K*R) x (K*R) system blkdiag(w*C_k) + rhoC/2*kron(H'H, I) (+ rhoC/2*I), rhoC = mean(rho) (:282-297)
+void Engine::par2_prepare_C_coupled(int m, int ctype, const aoadmm_options& opt) {
+  ModeInfo& mi = modes_[m];
+  TensorInfo& t = tensors_[mi.tensor];
+  Par2Block& b = t.p2;
+  const P2Dims d = b.dims();
+  ModeInfo& mA = modes_[t.modes[0]];
+  ModeInfo& mB = modes_[t.modes[1]];
+  AdmmCtl* ctl = ctl_of_mode(m);
+  const int con = mi.constrained ? 1 : 0;
+  b.rhosum.ensure(64);
+  par2_xkb(b.X.d(), mB.fac.d(), d, b.T1.d(), stream_);
+  par2_c_system(mA.fac.d(), b.T1.d(), mA.gram.d(), b.GB.d(), t.weight, has_ridge_ ? mi.ridge : 0.0,
+                opt.bsum ? opt.bsum_weight / 2 : 0.0, ctype == 0 ? 1 + con : 0, ctype == 1 ? 1 : 0, d, mi.fac.d(),
+                b.ac.d(), b.rhoc.d(), b.Lc.d(), ctl, stream_);
+  // max(rho) for the prox (:1424); mean(rho) takes the place of the scalar rho of a CP mode (:284, :712), sum(rho)
+  // weighs this mode in the Delta update (:736)
+  par2_rho_max(b.rhoc.d(), b.K, b.rhomax.d(), stream_, mi.rho.d(), b.rhosum.d());
+  t.last_pos = 2;                                                              // last_m(p) = 3
+  mi.Aeff = b.ac.d();
+  if (ctype == 1) {
+    const int n = b.K * b.R;
+    AO_REQUIRE(n <= kDenseMaxN, "PARAFAC2 C mode coupled with type 1: K*R = %d exceeds the dense-system limit %d", n, kDenseMaxN);
+    AO_REQUIRE(mi.hc == b.K, "coupling matrix of the PARAFAC2 C mode has %lld columns, the mode has %d rows", (long long)mi.hc, b.K);
+    if (!b.have_HtH) {
+      b.HtH.ensure((size_t)b.K * b.K * 8);
+      gemm_small(b.HtH.d(), b.K, mi.Ht.d(), mi.hc, mi.H.d(), mi.hr, b.K, (int)mi.hr, b.K, 0, coef(1.0), 0.0, nullptr, stream_);
+      b.have_HtH = true;
+    }
+    b.Mbig.ensure((size_t)n * n * 8); b.Minv.ensure((size_t)n * n * 8);
+    par2_c_big_system(b.Lc.d(), b.HtH.d(), mi.rho.d(), con, b.K, b.R, b.Mbig.d(), stream_);
+    dense_spd_inverse(b.Mbig.d(), b.Minv.d(), n, ctl, stream_);
+  }
 }
 
 // objective pieces of a PARAFAC2 block that do not go through the last_mttkrp shortcut (:1262-1264, :1355, :1337)
