@@ -623,117 +623,7 @@ __global__ void prox_tv_k(ColArgs a, int use_lds, const AdmmCtl* ctl) {
 static constexpr int kTvParMax = 4096;
 static constexpr int kTvThreads = 256;
 
-__global__ __launch_bounds__(kTvThreads) void prox_tv_par_k(ColArgs a, const double* warm, int64_t ldw,
-                                                            const AdmmCtl* ctl) {
-  CTL_GUARD(ctl);
-  extern __shared__ double dyn[];
-  __shared__ int scan[kTvThreads];
-  __shared__ int flag_merge, flag_split, nseg_sh;
-  const int n = (int)a.rows;
-  const int t = threadIdx.x;
-  const int r = blockIdx.x;
-  const double* vin = a.V + a.ldv * r;
-  double* z = a.Z + a.ldz * r;
-  const double lam = a.p0 / (a.rho[0] * a.rho_mul);
-  double* y = dyn;                                   // n
-  double* val = dyn + n;                             // n (segment values)
-  int* start = reinterpret_cast<int*>(dyn + 2 * n);  // n + 1
-  signed char* J = reinterpret_cast<signed char*>(start + n + 1);   // n
-  for (int i = t; i < n; i += kTvThreads) y[i] = vin[i];
-  if (!(lam > 0.0)) {
-    __syncthreads();
-    for (int i = t; i < n; i += kTvThreads) z[i] = y[i];
-    return;
-  }
-  if (warm) {
-    const double* w = warm + ldw * r;
-    for (int i = t; i < n - 1; i += kTvThreads) {
-      const double d = w[i + 1] - w[i];
-      J[i] = d > 0 ? 1 : (d < 0 ? -1 : 0);
-    }
-  } else {
-    for (int i = t; i < n - 1; i += kTvThreads) J[i] = 0;
-  }
-  if (t == 0 && n > 0) J[n - 1] = 0;
-  __syncthreads();
-  const int chunk = (n + kTvThreads - 1) / kTvThreads;
-  const int c0 = t * chunk, c1 = min(n, c0 + chunk);
-  const int max_rounds = 4 * n + 64;
-  bool converged = false;
-  for (int round = 0; round < max_rounds; ++round) {
-    // ---- 1. segment starts: i == 0 or a jump between i-1 and i
-    int cnt = 0;
-    for (int i = c0; i < c1; ++i) cnt += (i == 0 || J[i - 1] != 0) ? 1 : 0;
-    scan[t] = cnt;
-    if (t == 0) { flag_merge = 0; flag_split = 0; }
-    __syncthreads();
-    for (int off = 1; off < kTvThreads; off <<= 1) {          // inclusive Hillis-Steele scan
-      const int add = t >= off ? scan[t - off] : 0;
-      __syncthreads();
-      scan[t] += add;
-      __syncthreads();
-    }
-    int pos = scan[t] - cnt;
-    for (int i = c0; i < c1; ++i)
-      if (i == 0 || J[i - 1] != 0) start[pos++] = i;
-    if (t == kTvThreads - 1) { nseg_sh = scan[t]; start[scan[t]] = n; }
-    __syncthreads();
-    const int nseg = nseg_sh;
-    // ---- 2. segment values
-    for (int s = t; s < nseg; s += kTvThreads) {
-      const int sa = start[s], sb = start[s + 1] - 1;
-      double S = 0.0;
-      for (int i = sa; i <= sb; ++i) S += y[i];
-      const double sl = sa == 0 ? 0.0 : (double)J[sa - 1];
-      const double sr = sb == n - 1 ? 0.0 : (double)J[sb];
-      val[s] = (S + lam * (sr - sl)) / (double)(sb - sa + 1);
-    }
-    __syncthreads();
-    // ---- 3. merge jumps whose sign disagrees with the values on both sides
-    for (int s = t; s + 1 < nseg; s += kTvThreads) {
-      const int jp = start[s + 1] - 1;
-      if ((double)J[jp] * (val[s + 1] - val[s]) <= 0.0) { J[jp] = 0; flag_merge = 1; }
-    }
-    __syncthreads();
-    const int merged = flag_merge;
-    __syncthreads();                                   // everyone has read the flag before it is reset
-    if (merged) continue;
-    // ---- 4. split segments whose interior dual leaves [-lam, lam]
-    for (int s = t; s < nseg; s += kTvThreads) {
-      const int sa = start[s], sb = start[s + 1] - 1;
-      const double v = val[s];
-      double u = sa == 0 ? 0.0 : -lam * (double)J[sa - 1];
-      double worst = lam * (1.0 + 1e-13);
-      int widx = -1;
-      double wu = 0.0;
-      for (int i = sa; i < sb; ++i) {
-        u += y[i] - v;
-        const double au = fabs(u);
-        if (au > worst) { worst = au; widx = i; wu = u; }
-      }
-      if (widx >= 0) { J[widx] = wu > 0 ? -1 : 1; flag_split = 1; }
-    }
-    __syncthreads();
-    const int split = flag_split;
-    __syncthreads();
-    if (!split) { converged = true; break; }
-  }
-  if (converged) {
-    const int nseg = nseg_sh;
-    for (int s = t; s < nseg; s += kTvThreads) {
-      const int sa = start[s], sb = start[s + 1] - 1;
-      const double v = val[s];
-      for (int i = sa; i <= sb; ++i) z[i] = v;
-    }
-  } else {
-    __syncthreads();
-    if (t == 0) tv1d_condat_dev(y, val, n, lam);     // exact sequential fallback (val reused as output)
-    __syncthreads();
-    for (int i = t; i < n; i += kTvThreads) z[i] = val[i];
-  }
-}
-
-// Second form of the same split/merge iteration, built on prefix sums so that no step is sequential in a
+// The iteration is built on prefix sums so that no step is sequential in a
 // segment's length: with Pc[i] = sum_{t<i} (y_t - c) (c = mean(y), which keeps the prefix sums small) the value
 // of segment [sa, sb] is  c + (Pc[sb+1] - Pc[sa] + lam*(J[sb] - J[sa-1])) / len  and the dual at an interior
 // point is  u_i = -lam*J[sa-1] + (Pc[i+1] - Pc[sa]) - (v - c)*(i - sa + 1),  both O(1).  A round is: scan the

@@ -15,8 +15,6 @@ void transpose_convert(void* dst, int prec, int64_t pad_c, const double* src, in
                        hipStream_t s);
 // sum of squares of a padded tensor (padding is zero) -> slot (fp64), deterministic
 void tensor_sumsq(double* slot, const void* X, int prec, int64_t n, double* ws, hipStream_t s);
-// X *= alpha
-void tensor_scale(void* X, int prec, int64_t n, double alpha, hipStream_t s);
 
 // synthetic CP data: element (i,j,k) of the local block with global row i+row0:
 //   clean = sum_r A(i,r) B(j,r) C(k,r), A/B/C ~ U[0,1) from a counter-based generator;
@@ -38,9 +36,6 @@ size_t synth_ws_bytes();
 // regulariser value of constraints_to_prox.m (reg_func) on a factor matrix -> slot
 void reg_value(double* slot, int type, double p0, const double* X, int64_t rows, int R, double* ws,
                hipStream_t s);
-
-// uniform [0,1) fill (device RNG; used by tests/bench for factor initialisation on device)
-void fill_uniform(double* x, int64_t n, uint64_t seed, hipStream_t s);
 
 // Xp(j,k,i) = X(i,j,k), leading dimensions Ip (X) and Jp (Xp); padding rows of Xp are written as zeros
 void permute_231(const void* X, void* Xp, int prec, int64_t I, int64_t Ip, int64_t J, int64_t Jp, int64_t K,

@@ -102,17 +102,6 @@ void tensor_sumsq(double* slot, const void* X, int prec, int64_t n, double* ws, 
   AO_KERNEL_CHECK();
 }
 
-template <typename T>
-__global__ void tensor_scale_k(T* X, int64_t n, double alpha) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    X[i] = (T)((double)X[i] * alpha);
-}
-void tensor_scale(void* X, int prec, int64_t n, double alpha, hipStream_t s) {
-  if (prec == AOADMM_PREC_F32) tensor_scale_k<float><<<4096, 256, 0, s>>>((float*)X, n, alpha);
-  else tensor_scale_k<double><<<4096, 256, 0, s>>>((double*)X, n, alpha);
-  AO_KERNEL_CHECK();
-}
-
 // ---------------------------------------------------------------------------
 // counter-based generator: splitmix64 finaliser of (seed, stream, index)
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
@@ -134,13 +123,6 @@ __device__ __forceinline__ double gauss01(uint64_t seed, uint64_t idx) {
 __global__ void fill_uniform_k(double* x, int64_t n, uint64_t seed, uint64_t stream) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     x[i] = u01(seed, stream, (uint64_t)i);
-}
-void fill_uniform(double* x, int64_t n, uint64_t seed, hipStream_t s) {
-  int64_t blocks = cdiv(n, 256);
-  if (blocks > 4096) blocks = 4096;
-  if (blocks < 1) return;
-  fill_uniform_k<<<(unsigned)blocks, 256, 0, s>>>(x, n, seed, 7);
-  AO_KERNEL_CHECK();
 }
 void synth_factors(double* A, double* B, double* C, const SynthArgs& a, hipStream_t s) {
   fill_uniform_k<<<256, 256, 0, s>>>(A, a.I_full * a.R, a.seed, 1);

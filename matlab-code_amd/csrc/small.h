@@ -46,9 +46,6 @@ void atb_small(double* out, const double* A, int64_t lda, const double* B, int64
 // slot[0] = sum (x-y)^2 (y may be null) ; ws >= 64 doubles
 void sumsq_diff(double* slot, const double* x, const double* y, int64_t n, double* ws,
                 const AdmmCtl* ctl, hipStream_t s);
-// slot[0] = sum x.*y
-void dot(double* slot, const double* x, const double* y, int64_t n, double* ws, const AdmmCtl* ctl,
-         hipStream_t s);
 // Several independent reductions in one launch.  RT_SUMSQ_DIFF: sum (x-y)^2 (y may be null) over n;
 // RT_DOT: sum x.*y over n; RT_REG: value of the regulariser `aux` (AOADMM_C_* id: l1, l0, ridge, TV,
 // GL smoothness; constraints_to_prox.m reg_func) of the rows x R matrix x.  slot[0] = scale * sum.

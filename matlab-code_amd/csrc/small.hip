@@ -307,19 +307,6 @@ void sumsq_diff(double* slot, const double* x, const double* y, int64_t n, doubl
   reduce_fin_k<<<1, 64, 0, s>>>(slot, ws, nb, ctl);
   AO_KERNEL_CHECK();
 }
-void dot(double* slot, const double* x, const double* y, int64_t n, double* ws, const AdmmCtl* ctl,
-         hipStream_t s) {
-  const int nb = red_blocks(n);
-  if (nb == 1) {
-    reduce_part_k<1><<<1, 256, 0, s>>>(slot, x, y, n, ctl);
-    AO_KERNEL_CHECK();
-    return;
-  }
-  reduce_part_k<1><<<nb, 256, 0, s>>>(ws, x, y, n, ctl);
-  AO_KERNEL_CHECK();
-  reduce_fin_k<<<1, 64, 0, s>>>(slot, ws, nb, ctl);
-  AO_KERNEL_CHECK();
-}
 
 // ---------------------------------------------------------------------------
 // per-row forward/backward substitution: x*L' = a (forward), then x*L = y (backward)

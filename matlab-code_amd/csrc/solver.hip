@@ -2,6 +2,7 @@
 // functions/cmtf_fun_AOADMM.m:87-476 (outer loop), :625-695 / :904-983 (coupled ADMM
 // cases 0 and 4), :1213-1363 (objective), functions/evaluate_stopping_conditions.m.
 #include "solver.h"
+#include "device_utils.h"
 #include "em.h"
 #include "hosteig.h"
 
@@ -1126,17 +1127,13 @@ void Engine::update_uncoupled_cp_mode(int m, const aoadmm_options& opt) {
 // The six linear couplings (cmtf_fun_AOADMM.m:625-1075) in one form:  Tf_m(C_m) = Sd_m(Delta)
 //   type 0: C = Delta | 1: H*C = Delta | 2: C*H = Delta | 3: C = H*Delta | 4: C = Delta*H | 5: H*C = Delta*H2
 // Sd: the Delta-side image for mode m (shape img_rows x img_cols)
-static void image_d(double* dst, const CouplingInfo& ci, const double* D, const ModeInfo& mi, const AdmmCtl* ctl,
-                    hipStream_t s) {
+static const double* image_d(double* dst, const CouplingInfo& ci, const double* D, const ModeInfo& mi,
+                             const AdmmCtl* ctl, hipStream_t s) {
   switch (ci.type) {
-    case 3: gemm_small(dst, mi.rows, mi.H.d(), mi.hr, D, ci.rows, mi.rows, (int)ci.rows, mi.R, 0, coef(1.0), 0.0, ctl, s); break;
-    case 4: gemm_small(dst, mi.rows, D, ci.rows, mi.H.d(), mi.hr, ci.rows, (int)ci.cols, mi.R, 0, coef(1.0), 0.0, ctl, s); break;
-    case 5: gemm_small(dst, ci.rows, D, ci.rows, mi.H2.d(), mi.h2r, ci.rows, (int)ci.cols, mi.R, 0, coef(1.0), 0.0, ctl, s); break;
-    default: {
-      Coef c[1] = {coef(1.0)};
-      const double* x[1] = {D};
-      ew_lincomb(dst, ci.rows * ci.cols, 1, c, x, ctl, s);
-    }
+    case 3: gemm_small(dst, mi.rows, mi.H.d(), mi.hr, D, ci.rows, mi.rows, (int)ci.rows, mi.R, 0, coef(1.0), 0.0, ctl, s); return dst;
+    case 4: gemm_small(dst, mi.rows, D, ci.rows, mi.H.d(), mi.hr, ci.rows, (int)ci.cols, mi.R, 0, coef(1.0), 0.0, ctl, s); return dst;
+    case 5: gemm_small(dst, ci.rows, D, ci.rows, mi.H2.d(), mi.h2r, ci.rows, (int)ci.cols, mi.R, 0, coef(1.0), 0.0, ctl, s); return dst;
+    default: return D;                               // types 0, 1, 2: Sd is the identity
   }
 }
 // Tf: the factor-side image (same shape); types 0, 3, 4 are the identity and return F itself
@@ -1174,6 +1171,38 @@ __global__ void coupling_coefs_k(double* coef, const double* const* rhos, int n)
     for (int j = 0; j < n; ++j) coef[j] = 1.0 / s * rhos[j][0];
     coef[n] = s;
   }
+}
+
+// mu_Delta += Tf(C) - Sd(Delta) (:679 and the same line of every case) with the sums the coupling residuals need in
+// the same pass: out[0] = ||Tf(C) - Sd(Delta)||^2, out[1] = ||mu_Delta||^2, out[3] = ||den||^2 (den = Tf(C) or C,
+// :1099-1210); out[2] (the dual numerator) is filled by the caller.  One workgroup for n <= 2048, else per-block
+// partial sums added in block order by coupling_dual_fin_k.
+__global__ __launch_bounds__(256) void coupling_dual_k(double* muD, const double* tf, const double* td, int64_t ni,
+                                                       const double* den, int64_t nden, double* out, double* ws,
+                                                       const AdmmCtl* ctl) {
+  if (ctl != nullptr && ctl->active == 0) return;
+  __shared__ double sh4[4];
+  double s0 = 0, s1 = 0, s2 = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = first; i < ni; i += stride) {
+    const double g = tf[i] - td[i];
+    const double m = muD[i] + g;
+    muD[i] = m;
+    s0 += g * g; s1 += m * m;
+  }
+  for (int64_t i = first; i < nden; i += stride) s2 += den[i] * den[i];
+  s0 = block256_sum(s0, sh4); s1 = block256_sum(s1, sh4); s2 = block256_sum(s2, sh4);
+  if (threadIdx.x == 0) {
+    if (gridDim.x == 1) { out[0] = s0; out[1] = s1; out[3] = s2; }
+    else { double* w = ws + 3 * (int64_t)blockIdx.x; w[0] = s0; w[1] = s1; w[2] = s2; }
+  }
+}
+__global__ void coupling_dual_fin_k(double* out, const double* ws, int nb, const AdmmCtl* ctl) {
+  if (ctl != nullptr && ctl->active == 0) return;
+  if (threadIdx.x >= 3) return;
+  double t = 0.0;
+  for (int b = 0; b < nb; ++b) t += ws[3 * b + threadIdx.x];
+  out[threadIdx.x == 2 ? 3 : threadIdx.x] = t;
 }
 
 // Delta(k,:) = sum_j rho_j(k) * (C_j + mu_j)(k,:) / sum_j rho_j(k)   (:661-675): rho_j is a K-vector for a PARAFAC2
@@ -1269,23 +1298,25 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
     for (int j = 0; j < n; ++j) {
       ModeInfo& mi = modes_[ci.modes[j]];
       const int64_t nm = mi.rows * mi.R, ni = mi.img_rows * mi.img_cols;
-      image_d(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_);
+      // Sd(Delta): after the first inner iteration the image computed in the dual step below is still current
+      const double* TD = (it == 0 || ty == 0 || ty == 1 || ty == 2) ? image_d(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_)
+                                                                     : mi.TD.d();
       Par2Block* pb = pc_block(mi);
       if (pb && ty == 0) {
         // row k: A_inner = a_k + rho_k/2*(Delta - mu_Delta)(k,:) [+ rho_k/2*(Z - mu)(k,:)], solved with L_k (:638-645)
         Coef cf[4] = {coef(1.0), coef(-1.0), coef(1.0), coef(-1.0)};
-        const double* x[4] = {mi.TD.d(), mi.muD.d(), mi.Z.d(), mi.mu.d()};
+        const double* x[4] = {TD, mi.muD.d(), mi.Z.d(), mi.mu.d()};
         ew_lincomb(mi.RHS.d(), nm, mi.constrained ? 4 : 2, cf, x, ctl, stream_);
         par2_c_rowsolve(pb->ac.d(), pb->rhoc.d(), pb->Lc.d(), mi.RHS.d(), nullptr, 1, pb->dims_all(), mi.fac.d(), ctl, stream_);
         continue;
       }
       if (ty == 0 || ty == 3 || ty == 4) {
         Coef cf[5] = {coef(1.0), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), -0.5), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), -0.5)};
-        const double* x[5] = {mi.Aeff, mi.TD.d(), mi.muD.d(), mi.Z.d(), mi.mu.d()};
+        const double* x[5] = {mi.Aeff, TD, mi.muD.d(), mi.Z.d(), mi.mu.d()};
         ew_lincomb(mi.RHS.d(), nm, mi.constrained ? 5 : 3, cf, x, ctl, stream_);
       } else {
         Coef c2[2] = {coef(1.0), coef(-1.0)};
-        const double* x2[2] = {mi.TD.d(), mi.muD.d()};
+        const double* x2[2] = {TD, mi.muD.d()};
         ew_lincomb(mi.tmp.d(), ni, 2, c2, x2, ctl, stream_);                   // Sd(Delta) - mu_Delta
         const double* adj = adjoint_f(mi.TF.d(), ci, mi.tmp.d(), mi, ctl, stream_);
         Coef cf[4] = {coef(1.0), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), 0.5), coef(mi.rho.d(), -0.5)};
@@ -1389,23 +1420,30 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
       ModeInfo& mi = modes_[m];
       double* sl = resid + (int64_t)m * kResidPerMode;
       const int64_t nm = mi.rows * mi.R, ni = mi.img_rows * mi.img_cols;
-      image_d(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_);
+      const double* TD = image_d(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_);
       const double* tf = image_f(mi.TF.d(), ci, mi.fac.d(), mi, ctl, stream_);
-      Coef cf[3] = {coef(1.0), coef(1.0), coef(-1.0)};
-      const double* x[3] = {mi.muD.d(), tf, mi.TD.d()};
-      ew_lincomb(mi.muD.d(), ni, 3, cf, x, ctl, stream_);                      // mu_Delta += Tf(C) - Sd(Delta)
+      {
+        // mu_Delta += Tf(C) - Sd(Delta); sl[4] = ||Tf(C) - Sd(Delta)||^2, sl[5] = ||mu_Delta||^2, sl[7] = ||den||^2 with
+        // den = H*C (:1125) / C*H (:1143) for types 1, 2, else C
+        const bool img_den = ty == 1 || ty == 2;
+        int64_t nr = cdiv(std::max(ni, nm), 2048);
+        if (nr > 64) nr = 64;
+        coupling_dual_k<<<(unsigned)nr, 256, 0, stream_>>>(mi.muD.d(), tf, TD, ni, img_den ? tf : mi.fac.d(), img_den ? ni : nm,
+                                                           sl + 4, redws_.d(), ctl);
+        AO_KERNEL_CHECK();
+        if (nr > 1) {
+          coupling_dual_fin_k<<<1, 64, 0, stream_>>>(sl + 4, redws_.d(), (int)nr, ctl);
+          AO_KERNEL_CHECK();
+        }
+      }
       if (mi.constrained) {
         Par2Block* pb = pc_block(mi);                 // a C mode's prox gets max(rho) (:1423-1424)
         constraint_update(mi.prox, mi.fac.d(), mi.Z.d(), mi.mu.d(), mi.Zold.d(), mi.V.d(), mi.rows, mi.R,
                           pb ? pb->rhomax.d() : mi.rho.d(), 1.0, mi.proxws.d(), sl, redws_.d(), ctl, stream_);
       } else
         sumsq_diff(sl + 1, mi.fac.d(), nullptr, nm, redws_.d(), ctl, stream_);
-      sumsq_diff(sl + 4, tf, mi.TD.d(), ni, redws_.d(), ctl, stream_);
-      sumsq_diff(sl + 5, mi.muD.d(), nullptr, ni, redws_.d(), ctl, stream_);
-      image_d(mi.tmp.d(), ci, ci.dD.d(), mi, ctl, stream_);
-      sumsq_diff(sl + 6, mi.tmp.d(), nullptr, ni, redws_.d(), ctl, stream_);
-      // denominator of the primal coupling residual: ||H*C|| (:1125) / ||C*H|| (:1143) for types 1, 2, else ||C||
-      sumsq_diff(sl + 7, (ty == 1 || ty == 2) ? tf : mi.fac.d(), nullptr, (ty == 1 || ty == 2) ? ni : nm, redws_.d(), ctl, stream_);
+      const double* dimg = image_d(mi.tmp.d(), ci, ci.dD.d(), mi, ctl, stream_);
+      sumsq_diff(sl + 6, dimg, nullptr, ni, redws_.d(), ctl, stream_);
       fa.slots[j] = sl;
       fa.constrained[j] = mi.constrained ? 1 : 0;
       fa.coupled[j] = 1;
@@ -1492,9 +1530,9 @@ void Engine::eval_objective_enqueue(bool first) {
       CouplingInfo& ci = couplings_[mi.coupling];
       const size_t nimg = (size_t)std::max(nm, mi.img_rows * mi.img_cols) * sizeof(double);
       mi.TD.ensure(nimg); mi.TF.ensure(nimg);
-      image_d(mi.TD.d(), ci, ci.Delta.d(), mi, nullptr, stream_);
+      const double* td = image_d(mi.TD.d(), ci, ci.Delta.d(), mi, nullptr, stream_);
       const double* tf = image_f(mi.TF.d(), ci, mi.fac.d(), mi, nullptr, stream_);
-      add(RT_SUMSQ_DIFF, sm + 2, tf, mi.TD.d(), mi.img_rows * mi.img_cols);
+      add(RT_SUMSQ_DIFF, sm + 2, tf, td, mi.img_rows * mi.img_cols);
       if (tf != mi.fac.d()) add(RT_SUMSQ_DIFF, sm + 4, tf, nullptr, mi.img_rows * mi.img_cols);   // ||H*C|| / ||C*H||
     }
     if (rb.n >= kReduceBatchMax - 4) {           // many modes: flush and start the next batch
