@@ -136,6 +136,12 @@ typedef struct aoadmm_result {
   double *func_rel_missing;     /* MaxOuterIters+1 entries, [0] = NaN; may be NULL */
 } aoadmm_result;
 
+/* Progress report of options.Display = 'iter' (cmtf_fun_AOADMM.m:44-59, :462-468): called on the caller's thread
+ * from inside aoadmm_solve after the initial evaluation (iter = 0) and after every `every`-th outer iteration with
+ * f = {f_tensors, f_couplings, f_constraints, f_PAR2_couplings} and f_rel_missing (NaN without Z.miss).
+ * The callback must not throw and must not call back into the library. */
+typedef void (*aoadmm_progress_fn)(void* user, int iter, const double f[4], double f_rel_missing);
+
 /* ---- library / context ------------------------------------------------- */
 int aoadmm_abi_version(void);
 const char* aoadmm_last_error(void);
@@ -143,6 +149,8 @@ int aoadmm_device_count(int* n);
 int aoadmm_create(aoadmm_ctx** ctx, int device);
 int aoadmm_destroy(aoadmm_ctx* ctx);
 int aoadmm_synchronize(aoadmm_ctx* ctx);
+/* fn = NULL or every <= 0 switches the report off (options.DisplayIters is `every`) */
+int aoadmm_set_progress(aoadmm_ctx* ctx, aoadmm_progress_fn fn, void* user, int every);
 
 /* Multi-GPU (one process per GPU): rank 0 creates an id, the host layer
  * broadcasts it (torch.distributed / MPI / a file), every rank joins.  The CP

@@ -83,6 +83,11 @@ int aoadmm_synchronize(aoadmm_ctx* ctx) {
   });
 }
 
+int aoadmm_set_progress(aoadmm_ctx* ctx, aoadmm_progress_fn fn, void* user, int every) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->set_progress(fn, user, every); });
+}
+
 int aoadmm_comm_unique_id(char id[128]) {
   return guarded([&] {
     AO_REQUIRE(id != nullptr, "null pointer");

@@ -183,6 +183,7 @@ class Engine {
   // communicator
   void comm_init(const char id[128], int rank, int world);
   void comm_init_local(int key, int rank, int world);
+  void set_progress(aoadmm_progress_fn fn, void* user, int every) { progress_fn_ = fn; progress_user_ = user; progress_every_ = every; }
   void par2_gather_slabs(TensorInfo& t);
   bool sharded() const { return comm_ != nullptr || local_ != nullptr; }
   int rank() const { return rank_; }
@@ -248,6 +249,9 @@ class Engine {
   ncclComm_t comm_ = nullptr;
   std::shared_ptr<LocalGroup> local_;   // process-local group (threads of one process), see solver.hip
   int rank_ = 0, world_ = 1;
+  aoadmm_progress_fn progress_fn_ = nullptr;   // options.Display = 'iter'
+  void* progress_user_ = nullptr;
+  int progress_every_ = 0;
 
   AdmmCtl* ctl_of_mode(int m) { return ctls_.as<AdmmCtl>() + m; }
   AdmmCtl* ctl_of_coupling(int c) { return ctls_.as<AdmmCtl>() + n_modes_ + c; }

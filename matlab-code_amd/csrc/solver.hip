@@ -1723,6 +1723,8 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   if (out->time_at_it) out->time_at_it[0] = 0.0;
   double f_rel_missing = std::nan("");                                          // :30
   if (out->func_rel_missing) out->func_rel_missing[0] = f_rel_missing;
+  const bool report = progress_fn_ != nullptr && progress_every_ > 0;
+  if (report) progress_fn_(progress_user_, 0, f, f_rel_missing);               // :53-59
   const auto t0 = std::chrono::steady_clock::now();
 
   int iter = 1;
@@ -1791,6 +1793,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
       if (out->func_rel_missing) out->func_rel_missing[iter] = f_rel_missing;
       stop = stop && (f_rel_missing < opt.OuterRelTol);                        // :457-459
     }
+    if (report && iter % progress_every_ == 0) progress_fn_(progress_user_, iter, f, f_rel_missing);   // :462-468
     ++iter;
   }
   out->f_tensors = f[0]; out->f_couplings = f[1]; out->f_constraints = f[2]; out->f_PAR2_couplings = f[3];

@@ -422,6 +422,12 @@ def download_state(eng, Z, G):
     return out
 
 
+def _display_line(it, f, frm=None):
+    """One row of the iteration table, format of cmtf_fun_AOADMM.m:55-58."""
+    line = '%6d %12f %12f %12f %17f %12f' % (it, sum(f), f[0], f[1], f[2], f[3])
+    return line + (' %12f' % frm if frm is not None else '')
+
+
 def run_solver(eng, alg_options, nb_modes, has_missing=False):
     """`[Fac,out] = cmtf_fun_AOADMM(...)` (cmtf_AOADMM.m:193) -> the `out` struct (cmtf_fun_AOADMM.m:480-494)."""
     o = _make_options(alg_options)
@@ -434,8 +440,30 @@ def run_solver(eng, alg_options, nb_modes, has_missing=False):
         setattr(res, k, capi.dptr(b))
     res.innerIters = capi.dptr(inner)
     res.func_rel_missing = capi.dptr(frm)
-    capi.check(eng.lib.aoadmm_solve(eng.h, C.byref(o), C.byref(res)))
+    # options.Display (cmtf_fun_AOADMM.m:44-59, :462-468, :498-504): 'iter' lines come live from inside the solve
+    display = str(alg_options.get('Display', 'no')) if isinstance(alg_options, dict) else 'no'
+    every = int(alg_options.get('DisplayIters', 10)) if isinstance(alg_options, dict) else 10
+    rank0 = eng.comm_rank()[0] == 0
+    cb = None
+    if display in ('iter', 'final') and rank0:
+        print(' Iter  f total      f tensors      f couplings    f constraints    f PAR2 couplings' +
+              ('  f_rel_miss' if has_missing else ''))
+        print('------ ------------ -------------  -------------- ---------------- ----------------')
+    if display == 'iter' and rank0:
+        def _line(_user, it, f, frm):
+            print(_display_line(it, [f[i] for i in range(4)], frm if has_missing else None), flush=True)
+        cb = capi.PROGRESS_FN(_line)
+        capi.check(eng.lib.aoadmm_set_progress(eng.h, cb, None, every))
+    try:
+        capi.check(eng.lib.aoadmm_solve(eng.h, C.byref(o), C.byref(res)))
+    finally:
+        if cb is not None:
+            capi.check(eng.lib.aoadmm_set_progress(eng.h, capi.PROGRESS_FN(0), None, 0))
     it = int(res.OuterIterations)
+    if display in ('iter', 'final') and rank0:                                 # :496-503
+        print('%6d %12f %12f %12f %12f %12f' % (it, res.f_tensors + res.f_couplings + res.f_constraints + res.f_PAR2_couplings,
+                                                res.f_tensors, res.f_couplings, res.f_constraints, res.f_PAR2_couplings) +
+              (' %12f' % res.f_rel_missing if has_missing else ''))
     out = {
         'f_tensors': res.f_tensors, 'f_couplings': res.f_couplings, 'f_constraints': res.f_constraints,
         'f_PAR2_couplings': res.f_PAR2_couplings, 'f_rel_missing': res.f_rel_missing,

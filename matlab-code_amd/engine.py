@@ -82,6 +82,12 @@ class Engine:
     def comm_init_rank(self, uid, rank, world):
         capi.check(self.lib.aoadmm_comm_init_rank(self.h, uid, int(rank), int(world)))
 
+    def comm_rank(self):
+        """(rank, world) of this engine's communicator; (0, 1) without one."""
+        r, w = C.c_int(0), C.c_int(1)
+        capi.check(self.lib.aoadmm_comm_rank(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
     def comm_init_local(self, key, rank, world):
         """Bring-up/test transport: engines driven by threads of this process form group `key` (see aoadmm_hip.h)."""
         capi.check(self.lib.aoadmm_comm_init_local(self.h, int(key), int(rank), int(world)))

@@ -119,6 +119,16 @@ void put_state_maybe_cell(int field_id, int index, const mxArray* a) {
   }
 }
 
+struct ProgressState { bool has_missing = false; };
+void print_progress(void* user, int iter, const double f[4], double f_rel_missing) {
+  const ProgressState* ps = static_cast<const ProgressState*>(user);
+  if (ps->has_missing)
+    mexPrintf("%6d %12f %12f %12f %17f %12f %12f\n", iter, f[0] + f[1] + f[2] + f[3], f[0], f[1], f[2], f[3], f_rel_missing);
+  else
+    mexPrintf("%6d %12f %12f %12f %17f %12f\n", iter, f[0] + f[1] + f[2] + f[3], f[0], f[1], f[2], f[3]);
+  mexEvalString("drawnow;");                          // flush the command window while the solve is running
+}
+
 mxArray* get_like(int field_id, int index, const mxArray* ref) {
   if (!ref || mxIsEmpty(ref)) return mxCreateDoubleMatrix(0, 0, mxREAL);
   if (mxIsCell(ref)) {
@@ -322,9 +332,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     o.increase_factor_rhoBk = mxGetScalar(f);
   }
   o.use_dimtree = 1;
-  if (const mxArray* hip = field(opt, "hip", false))
+  if (const mxArray* hip = field(opt, "hip", false)) {
     if (const mxArray* f = field(hip, "no_permuted_copy", false)) o.no_permuted_copy = (int)mxGetScalar(f);
     if (const mxArray* f = field(hip, "par2_slab_sharding", false)) o.par2_slab_sharding = (int)mxGetScalar(f);
+  }
 
   // ---- solve
   const int n = o.MaxOuterIters + 1;
@@ -334,7 +345,18 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   res.func_val_conv = fv.data(); res.func_coupl_conv = fc.data(); res.func_constr_conv = fz.data();
   res.func_PAR2_coupl = fp.data(); res.time_at_it = tt.data(); res.innerIters = inner.data();
   res.func_rel_missing = frm.data();
-  check(aoadmm_solve(g_ctx, &o, &res));
+  // options.Display = 'iter': one table row every DisplayIters iterations, live (cmtf_fun_AOADMM.m:53-59, :462-468)
+  ProgressState ps;
+  ps.has_missing = has_missing;
+  const mxArray* disp = field(opt, "Display", false);
+  const bool live = disp && mxIsChar(disp) && str(disp) == "iter";
+  if (live) {
+    const mxArray* di = field(opt, "DisplayIters", false);
+    check(aoadmm_set_progress(g_ctx, &print_progress, &ps, di ? (int)mxGetScalar(di) : 10));
+  }
+  const int rc = aoadmm_solve(g_ctx, &o, &res);
+  if (live) (void)aoadmm_set_progress(g_ctx, nullptr, nullptr, 0);
+  check(rc);
 
   // ---- Fac: same fields as G (cmtf_AOADMM.m:193,197-206)
   plhs[0] = mxDuplicateArray(G);

@@ -36,25 +36,23 @@ function [G,out] = cmtf_fun_AOADMM_hip(Z,Znorm_const,G,fh,gh,lscalar,uscalar,opt
     end
     try
         tstart = tic;
-        [G,out] = aoadmm_mex(Zs, G, options);
-        if any(strcmp(options.Display,{'iter','final'}))   % cmtf_fun_AOADMM.m:44-59,462-468,498-504
-            has_missing = isfield(out,'func_rel_missing');
-            if has_missing
+        if any(strcmp(options.Display,{'iter','final'}))   % header, cmtf_fun_AOADMM.m:44-51
+            if isfield(Zs,'miss') && ~isempty(Zs.miss) && any(~cellfun(@isempty,Zs.miss))
                 fprintf(1,' Iter  f total      f tensors      f couplings    f constraints    f PAR2 couplings  f_rel_miss\n');
             else
                 fprintf(1,' Iter  f total      f tensors      f couplings    f constraints    f PAR2 couplings\n');
             end
             fprintf(1,'------ ------------ -------------  -------------- ---------------- ----------------\n');
-            its = 0:out.OuterIterations;
-            if strcmp(options.Display,'final'), its = out.OuterIterations; else, its = its(mod(its,options.DisplayIters)==0 | its==out.OuterIterations); end
-            for it = its
-                ft = out.func_val_conv(it+1); fc = out.func_coupl_conv(it+1);
-                fz = out.func_constr_conv(it+1); fp = out.func_PAR2_coupl(it+1);
-                if has_missing
-                    fprintf(1,'%6d %12f %12f %12f %17f %12f %12f\n', it, ft+fc+fz+fp, ft, fc, fz, fp, out.func_rel_missing(it+1));
-                else
-                    fprintf(1,'%6d %12f %12f %12f %17f %12f\n', it, ft+fc+fz+fp, ft, fc, fz, fp);
-                end
+        end
+        [G,out] = aoadmm_mex(Zs, G, options);   % with Display = 'iter' the gateway prints a row every DisplayIters iterations
+        if any(strcmp(options.Display,{'iter','final'}))   % final row, cmtf_fun_AOADMM.m:496-503
+            it = out.OuterIterations;
+            ft = out.func_val_conv(it+1); fc = out.func_coupl_conv(it+1);
+            fz = out.func_constr_conv(it+1); fp = out.func_PAR2_coupl(it+1);
+            if isfield(out,'func_rel_missing')
+                fprintf(1,'%6d %12f %12f %12f %12f %12f %12f\n', it, ft+fc+fz+fp, ft, fc, fz, fp, out.func_rel_missing(it+1));
+            else
+                fprintf(1,'%6d %12f %12f %12f %12f %12f\n', it, ft+fc+fz+fp, ft, fc, fz, fp);
             end
         end
         out.wall_time_hip = toc(tstart);

@@ -44,6 +44,8 @@ mxArray* mxCreateString(const char*);
 mxArray* mxDuplicateArray(const mxArray*);
 void mexErrMsgIdAndTxt(const char*, const char*, ...);
 int mexAtExit(void (*)(void));
+int mexPrintf(const char*, ...);
+int mexEvalString(const char*);
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]);
 #ifdef __cplusplus
 }

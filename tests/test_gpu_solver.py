@@ -324,3 +324,21 @@ def test_parafac2_C_mode_coupling_unsupported_types(pkg, eng):
     Z['coupling']['coupl_trafo_matrices'] = [np.eye(3), None, None, None, None, np.eye(3)]
     with pytest.raises(capi.UnsupportedOnDevice):
         run_both(pkg, eng, Z, io, options(MaxOuterIters=2))
+
+
+def test_display_iter_reports_live(pkg, eng, capsys):
+    """options.Display = 'iter' (cmtf_fun_AOADMM.m:44-59, :462-468, :496-503): header, iteration 0, every DisplayIters-th
+    iteration from inside the solve (aoadmm_set_progress), and the final row; the numbers are those of `out`."""
+    rng = np.random.default_rng(3)
+    Z, io, _ = cp_model((20, 12, 9), 3, rng, [('non-negativity',)] * 3)
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(7))
+    opt = options(MaxOuterIters=7, Display='iter', DisplayIters=2)
+    _, _, _, out = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=eng)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert lines[0].startswith(' Iter  f total') and lines[1].startswith('------')
+    rows = [ln.split() for ln in lines[2:]]
+    assert [int(r[0]) for r in rows] == [0, 2, 4, 6, 7]                 # 0, multiples of DisplayIters, final
+    for r in rows:
+        it = int(r[0])
+        assert abs(float(r[2]) - out['func_val_conv'][it]) < 5e-7       # printed with 6 decimals
+        assert abs(float(r[4]) - out['func_constr_conv'][it]) < 5e-7
