@@ -147,6 +147,12 @@ int aoadmm_abi_version(void);
 const char* aoadmm_last_error(void);
 int aoadmm_device_count(int* n);
 int aoadmm_create(aoadmm_ctx** ctx, int device);
+/* One process, several GPUs (a MATLAB session): the context owns one engine and one host thread per
+ * listed device, joined by RCCL; every call below is executed by all of them together and returns when the last is
+ * done, outputs come from rank 0.  The model is sharded exactly as with one process per GPU.  Listing a device more
+ * than once selects the host-staged bring-up transport of aoadmm_comm_init_local (that is how the one-GPU test box
+ * runs this path).  aoadmm_comm_init_* are not valid on such a context. */
+int aoadmm_create_multi(aoadmm_ctx** ctx, int n_devices, const int* devices);
 int aoadmm_destroy(aoadmm_ctx* ctx);
 int aoadmm_synchronize(aoadmm_ctx* ctx);
 /* fn = NULL or every <= 0 switches the report off (options.DisplayIters is `every`) */

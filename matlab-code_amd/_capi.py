@@ -23,7 +23,7 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_
 
 # every symbol include/aoadmm_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    'aoadmm_abi_version', 'aoadmm_last_error', 'aoadmm_device_count', 'aoadmm_create', 'aoadmm_destroy',
+    'aoadmm_abi_version', 'aoadmm_last_error', 'aoadmm_device_count', 'aoadmm_create', 'aoadmm_create_multi', 'aoadmm_destroy',
     'aoadmm_synchronize', 'aoadmm_set_progress', 'aoadmm_comm_unique_id', 'aoadmm_comm_init_rank', 'aoadmm_comm_init_local', 'aoadmm_comm_rank',
     'aoadmm_model_begin', 'aoadmm_model_set_mode', 'aoadmm_model_set_mode_slabs', 'aoadmm_model_add_cp',
     'aoadmm_model_add_par2', 'aoadmm_model_set_constraint', 'aoadmm_model_set_coupling',
@@ -91,6 +91,7 @@ def load_library():
     i64 = C.c_int64
     vp = C.c_void_p
     lib.aoadmm_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.aoadmm_create_multi.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int)]
     lib.aoadmm_destroy.argtypes = [vp]
     lib.aoadmm_synchronize.argtypes = [vp]
     lib.aoadmm_device_count.argtypes = [C.POINTER(C.c_int)]

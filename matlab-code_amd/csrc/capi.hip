@@ -2,19 +2,99 @@
 // leaves this file; every entry point returns a status and records the message.
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 
 #include "solver.h"
 #include "misc.h"
 
 using namespace aoadmm;
 
-struct aoadmm_ctx {
-  Engine* eng;
+static thread_local std::string g_last_error;
+
+// One process, several GPUs (the shape a MATLAB session needs: SURVEY 8b): the context owns one engine per device
+// and one host thread per engine.  Every model/data/state/solve call is handed to all workers at once -- the ranks
+// must enter the collectives inside those calls together -- and returns when the last worker is done.
+struct MultiCtx {
+  std::vector<std::unique_ptr<Engine>> eng;
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv_job, cv_done;
+  std::function<void(Engine&, int)> job;
+  uint64_t gen = 0;
+  int pending = 0;
+  bool quit = false;
+  std::vector<int> code;
+  std::vector<std::string> msg;
+
+  void worker(int r, int device) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::function<void(Engine&, int)> f;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_job.wait(lk, [&] { return quit || gen != seen; });
+        if (quit) return;
+        seen = gen;
+        f = job;
+      }
+      int c = AOADMM_OK;
+      std::string w;
+      try {
+        (void)hipSetDevice(device);
+        f(*eng[r], r);
+      } catch (const Error& e) { c = e.code; w = e.what(); }
+      catch (const std::bad_alloc&) { c = AOADMM_ERR_NOMEM; w = "host allocation failed"; }
+      catch (const std::exception& e) { c = AOADMM_ERR_INVALID; w = e.what(); }
+      catch (...) { c = AOADMM_ERR_INVALID; w = "unknown failure"; }
+      {
+        std::lock_guard<std::mutex> lk(m);
+        code[r] = c; msg[r] = w;
+        if (--pending == 0) cv_done.notify_all();
+      }
+    }
+  }
+  // run f on every engine concurrently; throws the first rank's failure
+  void run(const std::function<void(Engine&, int)>& f) {
+    {
+      std::unique_lock<std::mutex> lk(m);
+      job = f;
+      pending = (int)eng.size();
+      ++gen;
+      cv_job.notify_all();
+      cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    for (size_t r = 0; r < eng.size(); ++r)
+      if (code[r] != AOADMM_OK) throw Error(code[r], fmt("rank %d: %s", (int)r, msg[r].c_str()));
+  }
+  ~MultiCtx() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      quit = true;
+      cv_job.notify_all();
+    }
+    for (auto& t : th)
+      if (t.joinable()) t.join();
+  }
 };
 
-static thread_local std::string g_last_error;
+struct aoadmm_ctx {
+  Engine* eng;          // the engine (single device) or rank 0's engine (multi-device)
+  MultiCtx* multi;
+};
+
+// f(engine, rank) on the one engine, or on every engine of a multi-device context at once
+template <class F>
+static void on_engines(aoadmm_ctx* ctx, F&& f) {
+  if (ctx->multi) ctx->multi->run(std::function<void(Engine&, int)>(f));
+  else f(*ctx->eng, 0);
+}
 
 template <class F>
 static int guarded(F&& f) {
@@ -63,6 +143,41 @@ int aoadmm_create(aoadmm_ctx** ctx, int device) {
     Engine* e = new Engine(device);
     aoadmm_ctx* c = new aoadmm_ctx;
     c->eng = e;
+    c->multi = nullptr;
+    *ctx = c;
+  });
+}
+
+int aoadmm_create_multi(aoadmm_ctx** ctx, int n_devices, const int* devices) {
+  return guarded([&] {
+    AO_REQUIRE(ctx != nullptr && devices != nullptr && n_devices >= 1 && n_devices <= 64, "bad arguments");
+    *ctx = nullptr;
+    std::unique_ptr<MultiCtx> mc(new MultiCtx);
+    const int n = n_devices;
+    mc->eng.resize(n); mc->code.assign(n, AOADMM_OK); mc->msg.resize(n);
+    for (int r = 0; r < n; ++r) mc->eng[r].reset(new Engine(devices[r]));
+    for (int r = 0; r < n; ++r) mc->th.emplace_back(&MultiCtx::worker, mc.get(), r, devices[r]);
+    bool distinct = true;
+    for (int a = 0; a < n; ++a)
+      for (int b = a + 1; b < n; ++b) distinct = distinct && devices[a] != devices[b];
+    if (n > 1) {
+      if (distinct) {                                 // RCCL over xGMI, one rank per device
+        ncclUniqueId uid;
+        ncclResult_t r = ncclGetUniqueId(&uid);
+        if (r != ncclSuccess) throw Error(AOADMM_ERR_RCCL, fmt("ncclGetUniqueId failed: %s", ncclGetErrorString(r)));
+        char id[128];
+        std::memset(id, 0, sizeof id);
+        std::memcpy(id, &uid, sizeof(uid));
+        mc->run([&](Engine& e, int rank) { e.comm_init(id, rank, n); });
+      } else {                                        // a device listed twice: bring-up/test transport (see comm_init_local)
+        static std::atomic<int> next_key{1 << 20};
+        const int key = next_key++;
+        mc->run([&](Engine& e, int rank) { e.comm_init_local(key, rank, n); });
+      }
+    }
+    aoadmm_ctx* c = new aoadmm_ctx;
+    c->eng = mc->eng[0].get();
+    c->multi = mc.release();
     *ctx = c;
   });
 }
@@ -70,7 +185,8 @@ int aoadmm_create(aoadmm_ctx** ctx, int device) {
 int aoadmm_destroy(aoadmm_ctx* ctx) {
   return guarded([&] {
     if (!ctx) return;
-    delete ctx->eng;
+    if (ctx->multi) delete ctx->multi;                // joins the workers, destroys every engine
+    else delete ctx->eng;
     delete ctx;
   });
 }
@@ -78,14 +194,18 @@ int aoadmm_destroy(aoadmm_ctx* ctx) {
 int aoadmm_synchronize(aoadmm_ctx* ctx) {
   CTX_OR_FAIL(ctx);
   return guarded([&] {
-    AO_HIP(hipSetDevice(ctx->eng->device()));
-    AO_HIP(hipStreamSynchronize(ctx->eng->stream()));
+    on_engines(ctx, [&](Engine& e, int) {
+      AO_HIP(hipSetDevice(e.device()));
+      AO_HIP(hipStreamSynchronize(e.stream()));
+    });
   });
 }
 
 int aoadmm_set_progress(aoadmm_ctx* ctx, aoadmm_progress_fn fn, void* user, int every) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->set_progress(fn, user, every); });
+  return guarded([&] {                               // rank 0 reports
+    on_engines(ctx, [&](Engine& e, int r) { e.set_progress(r == 0 ? fn : nullptr, r == 0 ? user : nullptr, r == 0 ? every : 0); });
+  });
 }
 
 int aoadmm_comm_unique_id(char id[128]) {
@@ -100,11 +220,17 @@ int aoadmm_comm_unique_id(char id[128]) {
 }
 int aoadmm_comm_init_rank(aoadmm_ctx* ctx, const char id[128], int rank, int world) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->comm_init(id, rank, world); });
+  return guarded([&] {
+    AO_REQUIRE(!ctx->multi, "a multi-device context owns its communicator");
+    ctx->eng->comm_init(id, rank, world);
+  });
 }
 int aoadmm_comm_init_local(aoadmm_ctx* ctx, int key, int rank, int world) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->comm_init_local(key, rank, world); });
+  return guarded([&] {
+    AO_REQUIRE(!ctx->multi, "a multi-device context owns its communicator");
+    ctx->eng->comm_init_local(key, rank, world);
+  });
 }
 int aoadmm_comm_rank(aoadmm_ctx* ctx, int* rank, int* world) {
   CTX_OR_FAIL(ctx);
@@ -116,31 +242,31 @@ int aoadmm_comm_rank(aoadmm_ctx* ctx, int* rank, int* world) {
 
 int aoadmm_model_begin(aoadmm_ctx* ctx, int n_modes, int n_tensors, int n_couplings) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->model_begin(n_modes, n_tensors, n_couplings); });
+  return guarded([&] { on_engines(ctx, [&](Engine& e, int) { e.model_begin(n_modes, n_tensors, n_couplings); }); });
 }
 int aoadmm_model_set_mode(aoadmm_ctx* ctx, int mode, int64_t rows, int rank) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->set_mode(mode, rows, rank); });
+  return guarded([&] { on_engines(ctx, [&](Engine& e, int) { e.set_mode(mode, rows, rank); }); });
 }
 int aoadmm_model_set_mode_slabs(aoadmm_ctx* ctx, int mode, int K, const int64_t* rows_k, int rank) {
   CTX_OR_FAIL(ctx);
   return guarded([&] {
     AO_REQUIRE(rows_k != nullptr, "null pointer");
-    ctx->eng->set_mode_slabs(mode, K, rows_k, rank);
+    on_engines(ctx, [&](Engine& e, int) { e.set_mode_slabs(mode, K, rows_k, rank); });
   });
 }
 int aoadmm_model_add_cp(aoadmm_ctx* ctx, int p, int n, const int* modes, double weight) {
   CTX_OR_FAIL(ctx);
   return guarded([&] {
     AO_REQUIRE(modes != nullptr, "null pointer");
-    ctx->eng->add_cp(p, n, modes, weight);
+    on_engines(ctx, [&](Engine& e, int) { e.add_cp(p, n, modes, weight); });
   });
 }
 int aoadmm_model_add_par2(aoadmm_ctx* ctx, int p, const int* modes3, double weight) {
   CTX_OR_FAIL(ctx);
   return guarded([&] {
     AO_REQUIRE(modes3 != nullptr, "null pointer");
-    ctx->eng->add_par2(p, modes3, weight);
+    on_engines(ctx, [&](Engine& e, int) { e.add_par2(p, modes3, weight); });
   });
 }
 int aoadmm_model_set_constraint(aoadmm_ctx* ctx, int mode, int constraint, const double* params, int n_params,
@@ -148,32 +274,32 @@ int aoadmm_model_set_constraint(aoadmm_ctx* ctx, int mode, int constraint, const
   CTX_OR_FAIL(ctx);
   return guarded([&] {
     AO_REQUIRE(n_params == 0 || params != nullptr, "null parameters");
-    ctx->eng->set_constraint(mode, constraint, params, n_params, Lmat);
+    on_engines(ctx, [&](Engine& e, int) { e.set_constraint(mode, constraint, params, n_params, Lmat); });
   });
 }
 int aoadmm_model_set_coupling(aoadmm_ctx* ctx, int mode, int coupling, const double* H, int64_t hr, int64_t hc,
                               const double* H2, int64_t h2r, int64_t h2c) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->set_coupling(mode, coupling, H, hr, hc, H2, h2r, h2c); });
+  return guarded([&] { on_engines(ctx, [&](Engine& e, int) { e.set_coupling(mode, coupling, H, hr, hc, H2, h2r, h2c); }); });
 }
 int aoadmm_model_set_coupling_type(aoadmm_ctx* ctx, int coupling, int type) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->set_coupling_type(coupling, type); });
+  return guarded([&] { on_engines(ctx, [&](Engine& e, int) { e.set_coupling_type(coupling, type); }); });
 }
 int aoadmm_model_set_ridge(aoadmm_ctx* ctx, const double* ridge) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->set_ridge(ridge); });
+  return guarded([&] { on_engines(ctx, [&](Engine& e, int) { e.set_ridge(ridge); }); });
 }
 int aoadmm_model_end(aoadmm_ctx* ctx) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->model_end(); });
+  return guarded([&] { on_engines(ctx, [&](Engine& e, int) { e.model_end(); }); });
 }
 
 int aoadmm_tensor_upload(aoadmm_ctx* ctx, int p, const double* data, int precision) {
   CTX_OR_FAIL(ctx);
   return guarded([&] {
     AO_REQUIRE(data != nullptr, "null data");
-    ctx->eng->tensor_upload(p, data, precision, 0, -1);
+    on_engines(ctx, [&](Engine& e, int) { e.tensor_upload(p, data, precision, 0, -1); });
   });
 }
 int aoadmm_tensor_upload_rows(aoadmm_ctx* ctx, int p, const double* block, int64_t row_offset, int64_t local_rows,
@@ -181,58 +307,75 @@ int aoadmm_tensor_upload_rows(aoadmm_ctx* ctx, int p, const double* block, int64
   CTX_OR_FAIL(ctx);
   return guarded([&] {
     AO_REQUIRE(block != nullptr && local_rows > 0, "null/empty block");
-    ctx->eng->tensor_upload(p, block, precision, row_offset, local_rows);
+    on_engines(ctx, [&](Engine& e, int) { e.tensor_upload(p, block, precision, row_offset, local_rows); });
   });
 }
 int aoadmm_par2_slab_upload(aoadmm_ctx* ctx, int p, int k, const double* Xk) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->par2_slab_upload(p, k, Xk); });
+  return guarded([&] { on_engines(ctx, [&](Engine& e, int) { e.par2_slab_upload(p, k, Xk); }); });
 }
 int aoadmm_tensor_synth(aoadmm_ctx* ctx, int p, int rank, uint64_t seed, double noise, int precision) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->tensor_synth(p, rank, seed, noise, precision); });
+  return guarded([&] { on_engines(ctx, [&](Engine& e, int) { e.tensor_synth(p, rank, seed, noise, precision); }); });
 }
 int aoadmm_tensor_mask_upload(aoadmm_ctx* ctx, int p, const uint8_t* mask) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->tensor_mask_upload(p, mask); });
+  return guarded([&] { on_engines(ctx, [&](Engine& e, int) { e.tensor_mask_upload(p, mask); }); });
 }
 int aoadmm_par2_slab_mask_upload(aoadmm_ctx* ctx, int p, int k, const uint8_t* mask_k) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->par2_slab_mask_upload(p, k, mask_k); });
+  return guarded([&] { on_engines(ctx, [&](Engine& e, int) { e.par2_slab_mask_upload(p, k, mask_k); }); });
 }
 int aoadmm_tensor_normsq(aoadmm_ctx* ctx, int p, double* out) {
   CTX_OR_FAIL(ctx);
   return guarded([&] {
     AO_REQUIRE(out != nullptr, "null pointer");
-    *out = ctx->eng->tensor_normsq(p);
+    on_engines(ctx, [&](Engine& e, int r) {
+      const double v = e.tensor_normsq(p);           // collective: every rank computes, rank 0 answers
+      if (r == 0) *out = v;
+    });
   });
 }
 
 int aoadmm_state_set(aoadmm_ctx* ctx, int field, int index, int slab, const double* host, int64_t rows,
                      int64_t cols) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->state_set(field, index, slab, host, rows, cols); });
+  return guarded([&] { on_engines(ctx, [&](Engine& e, int) { e.state_set(field, index, slab, host, rows, cols); }); });
 }
 int aoadmm_state_get(aoadmm_ctx* ctx, int field, int index, int slab, double* host, int64_t rows, int64_t cols) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->state_get(field, index, slab, host, rows, cols); });
+  return guarded([&] {
+    ctx->eng->state_get(field, index, slab, host, rows, cols);   // multi-device: the state is replicated, rank 0 answers
+  });
 }
 
 int aoadmm_solve(aoadmm_ctx* ctx, const aoadmm_options* opt, aoadmm_result* out) {
   CTX_OR_FAIL(ctx);
   return guarded([&] {
     AO_REQUIRE(opt != nullptr && out != nullptr, "null options/result");
-    ctx->eng->solve(*opt, out);
+    on_engines(ctx, [&](Engine& e, int r) {
+      if (r == 0) { e.solve(*opt, out); return; }
+      aoadmm_result mine;                             // the other ranks keep their (identical) results to themselves
+      std::memset(&mine, 0, sizeof mine);
+      e.solve(*opt, &mine);
+    });
   });
 }
 int aoadmm_resident_mttkrp(aoadmm_ctx* ctx, int p, int tensor_mode, double* out_host_or_null, float* elapsed_ms) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->resident_mttkrp(p, tensor_mode, out_host_or_null, elapsed_ms); });
+  return guarded([&] {
+    on_engines(ctx, [&](Engine& e, int r) { e.resident_mttkrp(p, tensor_mode, r == 0 ? out_host_or_null : nullptr, r == 0 ? elapsed_ms : nullptr); });
+  });
 }
 int aoadmm_kernel_stats(aoadmm_ctx* ctx, int which, int reset, double* contract_ms, int64_t* contract_launches,
                         double* contract_bytes, double* contract_flops) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] { ctx->eng->kernel_stats(which, reset, contract_ms, contract_launches, contract_bytes, contract_flops); });
+  return guarded([&] {
+    on_engines(ctx, [&](Engine& e, int r) {
+      if (r == 0) e.kernel_stats(which, reset, contract_ms, contract_launches, contract_bytes, contract_flops);
+      else e.kernel_stats(which, reset, nullptr, nullptr, nullptr, nullptr);
+    });
+  });
 }
 
 // ---------------------------------------------------------------------------

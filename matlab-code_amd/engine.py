@@ -46,12 +46,18 @@ def constraint_descriptor(c):
 
 
 class Engine:
-    """One `aoadmm_ctx` (one GPU).  `Engine()` raises when no GPU / library is available."""
+    """One `aoadmm_ctx`: one GPU (`Engine(0)`), or several GPUs driven from this one process (`Engine([0, 1, 2, 3])`,
+    aoadmm_create_multi: one engine + one host thread per device inside the library, RCCL between them).
+    Raises when no GPU / library is available."""
 
     def __init__(self, device=0):
         self.lib = capi.load_library()
         self.h = C.c_void_p()
-        capi.check(self.lib.aoadmm_create(C.byref(self.h), int(device)))
+        if isinstance(device, (list, tuple)):
+            devs = (C.c_int * len(device))(*[int(d) for d in device])
+            capi.check(self.lib.aoadmm_create_multi(C.byref(self.h), len(device), devs))
+        else:
+            capi.check(self.lib.aoadmm_create(C.byref(self.h), int(device)))
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:

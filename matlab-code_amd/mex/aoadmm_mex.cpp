@@ -29,6 +29,8 @@
 namespace {
 
 aoadmm_ctx* g_ctx = nullptr;
+std::vector<int> g_devices;      // the device list g_ctx was created for
+bool g_at_exit = false;
 
 void at_exit() {
   if (g_ctx) {
@@ -162,7 +164,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   // Y = aoadmm_mex('unfold_gram', X, n): Gram matrix of the mode-n unfolding (cmtf_nvecs.m:40-56), n 1-based
   if (nrhs == 3 && mxIsChar(prhs[0])) {
     if (str(prhs[0]) != "unfold_gram") mexErrMsgIdAndTxt("cmtf:hip:usage", "unknown operation '%s'", str(prhs[0]).c_str());
-    if (!g_ctx) { check(aoadmm_create(&g_ctx, 0)); mexAtExit(at_exit); }
+    if (!g_ctx) {
+      check(aoadmm_create(&g_ctx, 0));
+      g_devices.assign(1, 0);
+      if (!g_at_exit) { mexAtExit(at_exit); g_at_exit = true; }
+    }
     const mxArray* X = prhs[1];
     const int nd = (int)mxGetNumberOfDimensions(X);
     const mwSize* d = mxGetDimensions(X);
@@ -176,14 +182,28 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   }
   if (nrhs != 3 || nlhs > 2) mexErrMsgIdAndTxt("cmtf:hip:usage", "usage: [Fac,out] = aoadmm_mex(Z, G, options)");
   const mxArray *Z = prhs[0], *G = prhs[1], *opt = prhs[2];
-  int device = 0, precision = AOADMM_PREC_F64;
+  // options.hip.device = d (one GPU) or options.hip.devices = [d0 d1 ...] (several GPUs from this one MATLAB process:
+  // aoadmm_create_multi, one engine + host thread per device inside the library, RCCL between them)
+  std::vector<int> devices(1, 0);
+  int precision = AOADMM_PREC_F64;
   if (const mxArray* hip = field(opt, "hip", false)) {
-    if (const mxArray* d = field(hip, "device", false)) device = (int)mxGetScalar(d);
+    if (const mxArray* d = field(hip, "device", false)) devices.assign(1, (int)mxGetScalar(d));
+    if (const mxArray* d = field(hip, "devices", false)) {
+      devices.clear();
+      for (mwSize i = 0; i < mxGetNumberOfElements(d); ++i) devices.push_back((int)mxGetDoubles(d)[i]);
+      if (devices.empty()) devices.assign(1, 0);
+    }
     if (const mxArray* p = field(hip, "precision", false)) precision = str(p) == "f32" ? AOADMM_PREC_F32 : AOADMM_PREC_F64;
   }
+  if (g_ctx && devices != g_devices) {               // another device list: start over
+    aoadmm_destroy(g_ctx);
+    g_ctx = nullptr;
+  }
   if (!g_ctx) {
-    check(aoadmm_create(&g_ctx, device));
-    mexAtExit(at_exit);
+    if (devices.size() == 1) check(aoadmm_create(&g_ctx, devices[0]));
+    else check(aoadmm_create_multi(&g_ctx, (int)devices.size(), devices.data()));
+    g_devices = devices;
+    if (!g_at_exit) { mexAtExit(at_exit); g_at_exit = true; }
   }
 
   // ---- model: Z.size, Z.modes, Z.model, Z.weights, Z.coupling, Z.constraints (example_script1:74-89)

@@ -7,7 +7,8 @@ function [G,out] = cmtf_fun_AOADMM_hip(Z,Znorm_const,G,fh,gh,lscalar,uscalar,opt
 %      by
 %        [Fac,out] = cmtf_fun_AOADMM_hip(Z,Znorm_const, G,fh,gh,lscalar,uscalar,options);
 % Nothing else changes: Z, the 'init' struct, init_options and options keep their fields; optional
-% engine settings live in options.hip (device = 0, precision = 'f64' | 'f32').
+% engine settings live in options.hip (device = 0 or devices = [0 1 ... 7] for several GPUs from this one
+% MATLAB process, precision = 'f64' | 'f32', par2_slab_sharding, no_permuted_copy).
 %
 % Function handles cannot cross to the GPU, so Z.prox_operators / Z.reg_func (cmtf_AOADMM.m:30-32) are
 % dropped and the MEX gateway re-reads the constraint descriptors Z.constraints{m}. Models the device

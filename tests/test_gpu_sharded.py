@@ -183,3 +183,39 @@ def test_slab_sharding_with_early_inner_exit(pkg):
     opt = options(MaxOuterIters=15, MaxInnerIters=8, innerRelPrTol_coupl=1e-2, innerRelDualTol_coupl=1e-2,
                   innerRelPrTol_constr=1e-2, innerRelDualTol_constr=1e-2)
     compare_par2(*run_sharded_par2(pkg, Z, io, opt, 2))
+
+
+# ---- one process, several engines behind ONE context (aoadmm_create_multi): the shape a MATLAB session uses ---------
+@pytest.mark.parametrize('ndev', [2, 3])
+def test_multi_device_context_single_caller(pkg, ndev):
+    """`Engine([0, 0])`: one context, one caller thread, the library fans every call out to its per-device worker
+    threads (device 0 listed several times selects the host-staged transport, RCCL would refuse it).  Same factors as
+    the oracle, same objective history, for a row-sharded CP block with TV + non-negativity."""
+    rng = np.random.default_rng(21)
+    Z, io, _ = cp_model((37, 14, 12), 3, rng, [('TV regularization', 0.01), ('non-negativity',), ('non-negativity',)])
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(7))
+    opt = options(MaxOuterIters=8)
+    _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
+    with pkg.Engine([0] * ndev) as e:
+        assert e.comm_rank() == (0, ndev)
+        _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=e)
+        compare(Fo, oo, Fg, og)
+        # the same context again with another model (coupled CP + PARAFAC2, slabs sharded over the engines)
+        Z2, io2 = script1_model(np.random.default_rng(12), dims=(20, 30, 40))
+        G2 = OA.init_coupled_AOADMM_CMTF({**Z2, 'prox_operators': None}, io2, rng=np.random.default_rng(7))
+        opt2 = options(MaxOuterIters=5)
+        _, Fo2, _, oo2 = OA.cmtf_AOADMM(Z2, alg_options=opt2, init=copy.deepcopy(G2))
+        opt2h = dict(opt2, hip=dict(par2_slab_sharding=1))
+        _, Fg2, _, og2 = pkg.cmtf_AOADMM(Z2, alg_options=opt2h, init=copy.deepcopy(G2), engine=e)
+        compare_par2(Fo2, oo2, Fg2, og2)
+
+
+def test_multi_device_context_reports_errors(pkg):
+    """A failure inside the workers comes back as a status + message naming the rank, not as a hang or a crash."""
+    capi = __import__('importlib').import_module('matlab-code_amd._capi')
+    with pkg.Engine([0, 0]) as e:
+        with pytest.raises(capi.AoadmmError) as ei:
+            capi.check(e.lib.aoadmm_model_begin(e.h, 0, 0, 0))
+        assert 'rank 0' in str(ei.value)
+        with pytest.raises(capi.AoadmmError):
+            e.comm_init_local(1, 0, 2)                 # the context owns its communicator
