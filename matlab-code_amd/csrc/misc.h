@@ -49,4 +49,8 @@ struct UnfoldGramArgs {
 size_t unfold_gram_ws_bytes(const UnfoldGramArgs& a);
 void unfold_gram(const UnfoldGramArgs& a, int prec, double* ws, double* out, hipStream_t s);
 
+// out(a + A*b, r) = Fa(a, r) * Fb(b, r)  (Khatri-Rao of two merged trailing modes, tensor storage order)
+void kr_merge(double* out, const double* Fa, int64_t lda, int64_t A, const double* Fb, int64_t ldb, int64_t B, int R,
+              hipStream_t s);
+
 }  // namespace aoadmm

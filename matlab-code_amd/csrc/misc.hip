@@ -349,4 +349,23 @@ void unfold_gram(const UnfoldGramArgs& a, int prec, double* ws, double* out, hip
   AO_KERNEL_CHECK();
 }
 
+// out(a + A*b, r) = Fa(a, r) * Fb(b, r): the Khatri-Rao factor of two merged trailing modes (column-major, the same
+// order in which the tensor stores them), used to present an N-way block to the 3-way EM kernel
+__global__ void kr_merge_k(double* out, const double* Fa, int64_t lda, int64_t A, const double* Fb, int64_t ldb, int64_t B,
+                           int R) {
+  const int64_t n = A * B * R;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t ab = e % (A * B);
+    const int r = (int)(e / (A * B));
+    out[e] = Fa[ab % A + lda * r] * Fb[ab / A + ldb * r];
+  }
+}
+void kr_merge(double* out, const double* Fa, int64_t lda, int64_t A, const double* Fb, int64_t ldb, int64_t B, int R,
+              hipStream_t s) {
+  int64_t nb = cdiv(A * B * R, 256);
+  if (nb > 4096) nb = 4096;
+  kr_merge_k<<<(unsigned)nb, 256, 0, s>>>(out, Fa, lda, A, Fb, ldb, B, R);
+  AO_KERNEL_CHECK();
+}
+
 }  // namespace aoadmm

@@ -31,6 +31,7 @@ struct CpBlock {
   // 3-way tensors: optional second copy Xp(j,k,i) = X(i,j,k) (leading dimension Jp), built on first use, so that
   // the pass that contracts mode 1 streams like the others (the tensor's size again in HBM; 288 GB per GPU)
   DevBuf Xp;
+  DevBuf emkr, emkr2;  // order > 3 with Z.miss: Khatri-Rao factor of the merged trailing modes (ping-pong)
   int64_t Jp = 0;
   bool has_xp = false, xp_refused = false;
   int nd = 0;

@@ -567,7 +567,6 @@ void Engine::tensor_mask_upload(int p, const uint8_t* mask) {
   TensorInfo& t = tensors_[p];
   CpBlock& b = t.blk;
   AO_REQUIRE(b.has_data, "upload Z.object{%d} before Z.miss{%d}", p + 1, p + 1);
-  AO_REQUIRE(b.nd == 2 || b.nd == 3, "Z.miss is supported for matrices and 3-way tensors on the device");
   AO_HIP(hipSetDevice(device_));
   const int64_t Iloc = b.dims[0], Ip = b.X.pad0, Ifull = b.full0;
   int64_t ncols = 1;
@@ -628,6 +627,22 @@ void Engine::em_pass_enqueue(int p, int update) {
   if (b.nd == 3) {
     const ModeInfo& m2 = modes_[t.modes[2]];
     a.C = m2.fac.d(); a.ldC = m2.rows; a.K = b.dims[2];
+  } else if (b.nd > 3) {
+    // order > 3: modes 3..N are merged into one, its factor is their Khatri-Rao product in storage order
+    int64_t Km = 1;
+    for (int i = 2; i < b.nd; ++i) Km *= b.dims[i];
+    b.emkr.ensure((size_t)Km * a.R * 8); b.emkr2.ensure((size_t)Km * a.R * 8);
+    const ModeInfo& m2 = modes_[t.modes[2]];
+    const double* cur = m2.fac.d();
+    int64_t curK = b.dims[2], ld = m2.rows;
+    double* bufs[2] = {b.emkr.d(), b.emkr2.d()};
+    for (int i = 3; i < b.nd; ++i) {
+      const ModeInfo& mn = modes_[t.modes[i]];
+      double* dst = bufs[(i - 3) & 1];
+      kr_merge(dst, cur, ld, curK, mn.fac.d(), mn.rows, b.dims[i], a.R, stream_);
+      cur = dst; curK *= b.dims[i]; ld = curK;
+    }
+    a.C = cur; a.ldC = curK; a.K = curK;
   }
   emws_.ensure(em_cp_ws_bytes(a.Ipad, a.K));
   em_cp_pass(a, b.X.prec, emws_.d(), em_slot(p), stream_);

@@ -103,10 +103,24 @@ def draw_model(seed):
     if rng.random() < 0.35:
         opt['bsum'] = 1
         opt['bsum_weight'] = float(rng.choice([1e-3, 1e-2]))
+    if seed >= 1000:                            # second family: ~20 % of the entries missing (Z.miss, EM imputation)
+        miss = []
+        for p_, obj in enumerate(objs):
+            if model[p_] == 'CP':
+                mk = rng.random(obj.shape) > 0.2
+                objs[p_] = np.where(mk, obj, 0.0)
+                miss.append(mk)
+            elif rng.random() < 0.5:
+                mks = [rng.random(x.shape) > 0.2 for x in obj]
+                objs[p_] = [np.where(m, x, 0.0) for m, x in zip(mks, obj)]
+                miss.append(mks)
+            else:
+                miss.append(None)
+        Z['miss'] = miss
     return Z, io, opt
 
 
-@pytest.mark.parametrize('seed', range(120))
+@pytest.mark.parametrize('seed', list(range(120)) + list(range(1000, 1040)))
 def test_random_model(pkg, eng, seed):
     Z, io, opt = draw_model(seed)
     Delta = None
