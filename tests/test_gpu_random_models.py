@@ -120,6 +120,52 @@ def draw_model(seed):
     return Z, io, opt
 
 
+def draw_transformed(seed):
+    """Third family (seeds 2000+): two CP blocks whose first modes are coupled with a transformation of type 1, 2, 3 or 5
+    (random sizes, random row-sampling / column-selecting matrices); fourth family (seeds 3000+): a CP block coupled to
+    the C mode of a PARAFAC2 block with type 0 or 1 (example_script14 family)."""
+    from helpers import par2_C_coupled_model, transformed_coupling_model
+    rng = np.random.default_rng(seed)
+    if seed >= 3000:
+        ctype = int(rng.integers(0, 2))
+        K = int(rng.integers(3, 9)) * 2
+        Z, io = par2_C_coupled_model(rng, ctype, noise=0.05, K=K, I2=int(rng.integers(6, 14)), Jk=int(rng.integers(6, 15)))
+        if rng.random() < 0.4:
+            Z['constrained_modes'][5] = 0
+            Z['constraints'][5] = None
+        if rng.random() < 0.4:
+            Z['ridge'] = [float(rng.choice([0.0, 1e-3])) for _ in range(6)]
+        Delta = None
+    else:
+        ctype = int(rng.choice([1, 2, 3, 5]))
+        Z, io = transformed_coupling_model(rng, ctype, noise=0.05)
+        if rng.random() < 0.5:                      # other constraints on the uncoupled modes
+            for m in (1, 2, 4, 5):
+                c = CATALOGUE[int(rng.integers(0, len(CATALOGUE)))] if rng.random() < 0.6 else None
+                Z['constraints'][m] = c
+                Z['constrained_modes'][m] = 0 if c is None else 1
+        Delta = [np.zeros((25, 4))] if ctype == 5 else None
+    opt = options(MaxOuterIters=int(rng.integers(4, 9)), MaxInnerIters=int(rng.integers(3, 7)))
+    if rng.random() < 0.3:
+        opt['bsum'] = 1
+        opt['bsum_weight'] = 1e-3
+    return Z, io, opt, Delta
+
+
+@pytest.mark.parametrize('seed', list(range(2000, 2030)) + list(range(3000, 3030)))
+def test_random_coupled_model(pkg, eng, seed):
+    Z, io, opt, Delta = draw_transformed(seed)
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, Delta=Delta, rng=np.random.default_rng(seed))
+    try:
+        _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
+    except np.linalg.LinAlgError:
+        pytest.skip('the drawn model hits a singular system in the reference algorithm itself')
+    _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=eng)
+    for key in ('DeltaB', 'P', 'mu_DeltaB'):
+        Fo.setdefault(key, {}); Fg.setdefault(key, {})
+    compare_par2(Fo, oo, Fg, og, tol=1e-7)
+
+
 @pytest.mark.parametrize('seed', list(range(120)) + list(range(1000, 1040)))
 def test_random_model(pkg, eng, seed):
     Z, io, opt = draw_model(seed)
