@@ -196,3 +196,42 @@ def test_random_model(pkg, eng, seed):
             assert any(np.isclose(a[i], b[i] * q, rtol=1e-6, atol=1e-12) for q in ratios), (k, i, a[i], b[i])
             og[k][i] = oo[k][i]
     compare_par2(Fo, oo, Fg, og, tol=1e-7)
+
+
+@pytest.fixture(scope='module')
+def eng2(pkg):
+    """Two engines behind one context (aoadmm_create_multi, device 0 listed twice): every model is row-sharded."""
+    with pkg.Engine([0, 0]) as e:
+        yield e
+
+
+@pytest.mark.parametrize('seed', list(range(0, 40)) + list(range(1000, 1020)) + list(range(2000, 2010)) + list(range(3000, 3010)))
+def test_random_model_sharded_over_two_engines(pkg, eng2, seed):
+    """The same draws through the N = 2 data path: CP blocks row-sharded, PARAFAC2 blocks slab-sharded where allowed."""
+    Delta = None
+    if seed >= 2000:
+        Z, io, opt, Delta = draw_transformed(seed)
+    else:
+        Z, io, opt = draw_model(seed)
+        if Z['coupling']['coupling_type'] == [4]:
+            fm = Z['coupling']['lin_coupled_modes'].index(1)
+            R = Z['coupling']['coupl_trafo_matrices'][fm].shape[1]
+            Delta = [np.random.default_rng(seed).random((Z['size'][fm], R + 1))]
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, Delta=Delta, rng=np.random.default_rng(seed))
+    try:
+        _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
+    except np.linalg.LinAlgError:
+        pytest.skip('the drawn model hits a singular system in the reference algorithm itself')
+    opt = dict(opt, hip=dict(par2_slab_sharding=1))
+    _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=eng2)
+    for key in ('DeltaB', 'P', 'mu_DeltaB'):
+        Fo.setdefault(key, {}); Fg.setdefault(key, {})
+    nmodes = len(Z['size'])
+    for k in ('func_constr_conv', 'func_coupl_conv'):          # the non-zero-count quirk, see test_random_model
+        a, b = np.asarray(og[k], dtype=float), np.asarray(oo[k], dtype=float)
+        for i in range(len(a)):
+            if not np.isclose(a[i], b[i], rtol=1e-7, atol=1e-10):
+                ratios = [n1 / n2 for n1 in range(1, nmodes + 1) for n2 in range(1, nmodes + 1)]
+                assert any(np.isclose(a[i], b[i] * q, rtol=1e-6, atol=1e-12) for q in ratios), (k, i, a[i], b[i])
+                og[k][i] = oo[k][i]
+    compare_par2(Fo, oo, Fg, og, tol=1e-7)
