@@ -75,3 +75,18 @@ def test_host_layer_rejects_what_the_device_path_does_not_cover(pkg):
     with pytest.raises(ValueError):
         pkg.constraint_descriptor(('no such constraint',))
     assert pkg.row_block(2000, 8, 7) == (1750, 250) and pkg.row_block(10, 4, 3) == (9, 1)
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """The boundary is a C ABI: include/aoadmm_hip.h must compile as C99 (no C++ leaks) and a plain-C caller
+    (examples/solve_cp.c, the call sequence of a MEX gateway) must link against the library.  Compute needs a GPU."""
+    import subprocess
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "aoadmm_hip.h"\nint main(void) { return aoadmm_abi_version() == 0; }\n')
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only',
+                    '-I', os.path.join(ROOT, 'include'), str(src)], check=True)
+    exe = tmp_path / 'solve_cp'
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-O1', '-I', os.path.join(ROOT, 'include'),
+                    os.path.join(ROOT, 'examples', 'solve_cp.c'), '-L', os.path.join(ROOT, 'matlab-code_amd'),
+                    '-laoadmm_hip', '-lm', '-o', str(exe)], check=True)
+    assert exe.exists()

@@ -179,3 +179,16 @@ def test_cell_state_one_slab_at_a_time_equals_all_slabs(pkg, eng):
         o += c.size
     with pytest.raises(Exception):                                        # wrong total row count is rejected
         capi.check(eng.lib.aoadmm_state_set(eng.h, capi.F_FAC, 1, capi.ALL_SLABS, capi.dptr(packed2), rows - 1, R))
+
+
+def test_plain_c_caller_runs(tmp_path):
+    """examples/solve_cp.c built with gcc and run as its own process: the C ABI needs nothing from Python or C++."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / 'solve_cp'
+    subprocess.run(['gcc', '-std=c99', '-O2', '-I', os.path.join(root, 'include'), os.path.join(root, 'examples', 'solve_cp.c'),
+                    '-L', os.path.join(root, 'matlab-code_amd'), '-laoadmm_hip', '-lm', '-o', str(exe)], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(root, 'matlab-code_amd') + ':' + os.environ.get('LD_LIBRARY_PATH', ''))
+    out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert 'RESULT ok' in out.stdout, out.stdout
