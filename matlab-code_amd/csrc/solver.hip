@@ -54,6 +54,7 @@ Engine::~Engine() {
 // ---------------------------------------------------------------------------
 void Engine::comm_init(const char id[128], int rank, int world) {
   AO_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world %d/%d", rank, world);
+  AO_REQUIRE(id != nullptr || world == 1, "a communicator of %d ranks needs the id from aoadmm_comm_unique_id", world);
   AO_HIP(hipSetDevice(device_));
   if (comm_) { (void)ncclCommDestroy(comm_); comm_ = nullptr; }
   local_.reset();
