@@ -60,10 +60,11 @@ void par2_b_finalize(const double* norms, const P2Dims& d, int use_constr, AdmmC
                      double* part4, const P2AllReduce& allreduce);
 
 // mode C: a(k,r) = w * sum_i A(i,r) T1[k](i,r) ; C_k = GA .* GB[k] ; rho_k ; B_k (+rho_k/2 I if constrained) ; chol  (:221-240)
-// nrho = how many rho_k/2*I terms the system gets (constraint, exact coupling :262-264); raw = 1: L receives B_k itself
+// nrho = how many rho_k/2*I terms the system gets (constraint, exact coupling :262-264); Madd (R x R, optional) enters
+// as + rho_k/2*Madd (coupling type 2: H*H', :307); raw = 1: L receives B_k itself
 void par2_c_system(const double* A, const double* T1, const double* GA, const double* GB, double w, double ridge,
                    double bsum_half, int nrho, int raw, const P2Dims& d, const double* Cfac, double* a, double* rho,
-                   double* L, AdmmCtl* ctl, hipStream_t s);
+                   double* L, AdmmCtl* ctl, hipStream_t s, const double* Madd = nullptr);
 // rhomax = max_k rho_k (:1424); separate because a slab-sharded block gathers rho first
 void par2_rho_max(const double* rho, int K, double* rhomax, hipStream_t s, double* rhomean = nullptr,
                   double* rhosum = nullptr);

@@ -524,8 +524,8 @@ void par2_b_finalize(const double* norms, const P2Dims& d, int use_constr, AdmmC
 // C mode
 // ---------------------------------------------------------------------------
 __global__ void par2_c_system_k(const double* A, const double* T1, const double* GA, const double* GB, double w,
-                                double ridge, double bsum_half, int nrho, int raw, P2Dims d, const double* Cfac,
-                                double* a, double* rho, double* L, AdmmCtl* ctl) {
+                                double ridge, double bsum_half, int nrho, int raw, const double* Madd, P2Dims d,
+                                const double* Cfac, double* a, double* rho, double* L, AdmmCtl* ctl) {
   extern __shared__ double sh[];
   __shared__ double rk;
   const int k = d.k0 + blockIdx.x, R = d.R, I = d.I;
@@ -546,6 +546,7 @@ __global__ void par2_c_system_k(const double* A, const double* T1, const double*
   for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
     double b = w * sh[e];
     if (e % R == e / R) b += ridge + bsum_half + nrho * (rk / 2);   // :224-239 ; coupled: :262-264
+    if (Madd) b += rk / 2 * Madd[e];                                 // coupling type 2: + rho_k/2 * H*H'  (:307)
     sh[e] = b;
   }
   __syncthreads();
@@ -569,9 +570,9 @@ __global__ void par2_max_k(const double* x, int n, double* out, double* mean, do
 }
 void par2_c_system(const double* A, const double* T1, const double* GA, const double* GB, double w, double ridge,
                    double bsum_half, int nrho, int raw, const P2Dims& d, const double* Cfac, double* a, double* rho,
-                   double* L, AdmmCtl* ctl, hipStream_t s) {
+                   double* L, AdmmCtl* ctl, hipStream_t s, const double* Madd) {
   par2_c_system_k<<<d.k1 - d.k0, kP2Threads, (size_t)d.R * d.R * sizeof(double), s>>>(A, T1, GA, GB, w, ridge, bsum_half,
-                                                                            nrho, raw, d, Cfac, a, rho, L, ctl);
+                                                                            nrho, raw, Madd, d, Cfac, a, rho, L, ctl);
   AO_KERNEL_CHECK();
 }
 void par2_rho_max(const double* rho, int K, double* rhomax, hipStream_t s, double* rhomean, double* rhosum) {

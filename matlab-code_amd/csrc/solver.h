@@ -101,7 +101,7 @@ struct Par2Block {
   int k0 = 0, k1 = 0;
   DevBuf psum;                    // R*R+1 partial sums of DeltaB, then 4 residual means
   // coupled C mode: sum(rho_k); H'H, the (K*R)^2 system and its inverse for coupling type 1 (:282-297)
-  DevBuf rhosum, HtH, Mbig, Minv;
+  DevBuf rhosum, HtH, Mbig, Minv, Hs;   // Hs = diag(rho)*H for coupling type 3
   bool have_HtH = false;
   P2Dims dims() const {
     P2Dims d;
@@ -241,6 +241,7 @@ class Engine {
   DevBuf ctls_;          // AdmmCtl[n_modes + n_couplings]
   DevBuf slots_;         // objective scalars
   DevBuf redws_;         // reduction workspace
+  DevBuf ones_;          // a device 1.0 (unit weight where a kernel expects a rho pointer)
   DevBuf emws_;          // EM pass partial sums
   bool allow_xp_ = true;  // options.hip.no_permuted_copy
   DevBuf atbws_;

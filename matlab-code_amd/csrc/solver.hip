@@ -39,6 +39,9 @@ Engine::Engine(int device) : device_(device) {
   AO_HIP(hipSetDevice(device));
   AO_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   redws_.alloc(4096 * sizeof(double));
+  ones_.alloc(sizeof(double));
+  const double one = 1.0;
+  AO_HIP(hipMemcpy(ones_.p, &one, sizeof one, hipMemcpyHostToDevice));
 }
 
 Engine::~Engine() {
@@ -289,8 +292,13 @@ void Engine::model_end() {
     AO_REQUIRE(!ci.modes.empty(), "coupling %d couples no mode", c);
     AO_REQUIRE(ci.modes.size() <= 8, "more than 8 modes in one coupling");
     for (int m : ci.modes)
-      if (tensors_[modes_[m].tensor].par2 && modes_[m].pos == 2 && ci.type != 0 && ci.type != 1)
-        throw Error(AOADMM_ERR_UNSUPPORTED, fmt("coupling type %d of a PARAFAC2 C mode is not in the device path (types 0 and 1 are; use the MATLAB path)", ci.type));
+      if (tensors_[modes_[m].tensor].par2 && modes_[m].pos == 2 && ci.type == 5)
+        throw Error(AOADMM_ERR_UNSUPPORTED, "coupling type 5 of a PARAFAC2 C mode is not in the device path (types 0-4 are; use the MATLAB path)");
+    if (ci.type == 4) {                       // :945-961 keeps one PARAFAC2 term apart (AAA); two would overwrite each other
+      int npc = 0;
+      for (int m : ci.modes) npc += (tensors_[modes_[m].tensor].par2 && modes_[m].pos == 2) ? 1 : 0;
+      if (npc > 1) throw Error(AOADMM_ERR_UNSUPPORTED, "coupling type 4 with more than one PARAFAC2 C mode is not supported");
+    }
     const ModeInfo& m0 = modes_[ci.modes[0]];
     auto need_H = [&](int m) { AO_REQUIRE(modes_[m].hr > 0, "Coupling matrix for mode %d is missing.", m + 1); };
     switch (ci.type) {
@@ -1239,6 +1247,50 @@ __global__ void coupling_rowmean_k(double* Delta, RowMeanArgs a, const AdmmCtl* 
   }
 }
 
+// out(k,c) = rho_k * in(k,c)  (rows of a K x cols matrix scaled by the rho vector of a PARAFAC2 C mode)
+__global__ void rows_scale_k(double* out, const double* in, const double* rho, int64_t rows, int64_t cols,
+                             const AdmmCtl* ctl) {
+  if (ctl != nullptr && ctl->active == 0) return;
+  const int64_t tot = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = rho[e % rows] * in[e];
+}
+static void rows_scale(double* out, const double* in, const double* rho, int64_t rows, int64_t cols, const AdmmCtl* ctl,
+                       hipStream_t s) {
+  int64_t nb = cdiv(rows * cols, 256);
+  if (nb > 1024) nb = 1024;
+  rows_scale_k<<<(unsigned)nb, 256, 0, s>>>(out, in, rho, rows, cols, ctl);
+  AO_KERNEL_CHECK();
+}
+// Delta(k,:) = BB(k,:) / (AA + rho_k*AAA)   (:957-961): one workgroup per row, q x q system in LDS
+__global__ void delta_rowwise_solve_k(double* Delta, const double* BB, int64_t rows, int q, const double* AA,
+                                      const double* AAA, const double* rho, AdmmCtl* ctl) {
+  if (ctl->active == 0) return;
+  extern __shared__ double sh[];                      // q*q matrix, then q right-hand side
+  double* M = sh;
+  double* x = sh + q * q;
+  const int64_t k = blockIdx.x;
+  for (int e = threadIdx.x; e < q * q; e += blockDim.x) M[e] = AA[e] + rho[k] * AAA[e];
+  for (int c = threadIdx.x; c < q; c += blockDim.x) x[c] = BB[k + rows * c];
+  __syncthreads();
+  const bool ok = chol_lds(M, q);
+  if (!ok) { if (threadIdx.x == 0) ctl->notpd = 1; return; }
+  if (threadIdx.x == 0) {                             // x * inv(L*L'): forward with L, backward with L'
+    for (int c = 0; c < q; ++c) {
+      double v = x[c];
+      for (int p = 0; p < c; ++p) v -= M[c + q * p] * x[p];
+      x[c] = v / M[c + q * c];
+    }
+    for (int c = q - 1; c >= 0; --c) {
+      double v = x[c];
+      for (int p = c + 1; p < q; ++p) v -= M[p + q * c] * x[p];
+      x[c] = v / M[c + q * c];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < q; c += blockDim.x) Delta[k + rows * c] = x[c];
+}
+
 struct AAArgs { const double* H[8]; const double* rho[8]; int R[8]; int n; int Rc; };
 __global__ void coupling_AA_k(double* AA, AAArgs a) {
   // AA = sum_j rho_j * H_j * H_j'   (:941-954 ; :1033-1047 with H2 and the common rhoC)
@@ -1297,16 +1349,22 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
     coupling_coefs_k<<<1, 64, 0, stream_>>>(ci.coef.d(), rho_ptrs.as<const double*>(), n);
     AO_KERNEL_CHECK();
   } else if (ty == 4 || ty == 5) {
-    AAArgs aa;
-    aa.n = n; aa.Rc = (int)ci.cols;
+    AAArgs aa, aaa;                                   // aaa: the PARAFAC2 C mode's H*H' kept apart (:946-948)
+    aa.n = 0; aa.Rc = (int)ci.cols; aaa.n = 0; aaa.Rc = (int)ci.cols;
     for (int j = 0; j < n; ++j) {
       const ModeInfo& mj = modes_[ci.modes[j]];
-      aa.H[j] = ty == 4 ? mj.H.d() : mj.H2.d();
-      aa.rho[j] = ty == 4 ? hp[j] : rho_last;
-      aa.R[j] = mj.R;
+      AAArgs& dst = (ty == 4 && pc_block(mj)) ? aaa : aa;
+      dst.H[dst.n] = ty == 4 ? mj.H.d() : mj.H2.d();
+      dst.rho[dst.n] = (&dst == &aaa) ? ones_.d() : (ty == 4 ? hp[j] : rho_last);
+      dst.R[dst.n] = mj.R;
+      dst.n++;
     }
     coupling_AA_k<<<1, 256, 0, stream_>>>(ci.AA.d(), aa);
     AO_KERNEL_CHECK();
+    if (aaa.n > 0) {                                  // LAA holds AAA; the per-row systems are factored in the Delta step
+      coupling_AA_k<<<1, 256, 0, stream_>>>(ci.LAA.d(), aaa);
+      AO_KERNEL_CHECK();
+    } else
     chol_only(ci.LAA.d(), ci.AA.d(), (int)ci.cols, ctl, stream_);
   }
   for (int it = 0; it < opt.MaxInnerIters; ++it) {
@@ -1318,11 +1376,22 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
       const double* TD = (it == 0 || ty == 0 || ty == 1 || ty == 2) ? image_d(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_)
                                                                      : mi.TD.d();
       Par2Block* pb = pc_block(mi);
-      if (pb && ty == 0) {
-        // row k: A_inner = a_k + rho_k/2*(Delta - mu_Delta)(k,:) [+ rho_k/2*(Z - mu)(k,:)], solved with L_k (:638-645)
-        Coef cf[4] = {coef(1.0), coef(-1.0), coef(1.0), coef(-1.0)};
-        const double* x[4] = {TD, mi.muD.d(), mi.Z.d(), mi.mu.d()};
-        ew_lincomb(mi.RHS.d(), nm, mi.constrained ? 4 : 2, cf, x, ctl, stream_);
+      if (pb && ty != 1) {
+        // row k: A_inner = a_k + rho_k/2*Tf'(Sd(Delta) - mu_Delta)(k,:) [+ rho_k/2*(Z - mu)(k,:)], solved with L_k
+        // (:638-645, :785-792, :850-857, :916-923); Tf' is the identity except for type 2 (right-multiplication by H')
+        if (ty == 2) {
+          Coef c2[2] = {coef(1.0), coef(-1.0)};
+          const double* x2[2] = {TD, mi.muD.d()};
+          ew_lincomb(mi.tmp.d(), ni, 2, c2, x2, ctl, stream_);
+          const double* adj = adjoint_f(mi.TF.d(), ci, mi.tmp.d(), mi, ctl, stream_);
+          Coef cf[3] = {coef(1.0), coef(1.0), coef(-1.0)};
+          const double* x[3] = {adj, mi.Z.d(), mi.mu.d()};
+          ew_lincomb(mi.RHS.d(), nm, mi.constrained ? 3 : 1, cf, x, ctl, stream_);
+        } else {
+          Coef cf[4] = {coef(1.0), coef(-1.0), coef(1.0), coef(-1.0)};
+          const double* x[4] = {TD, mi.muD.d(), mi.Z.d(), mi.mu.d()};
+          ew_lincomb(mi.RHS.d(), nm, mi.constrained ? 4 : 2, cf, x, ctl, stream_);
+        }
         par2_c_rowsolve(pb->ac.d(), pb->rhoc.d(), pb->Lc.d(), mi.RHS.d(), nullptr, 1, pb->dims_all(), mi.fac.d(), ctl, stream_);
         continue;
       }
@@ -1360,13 +1429,13 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
       const double* x1[1] = {ci.Delta.d()};
       ew_lincomb(ci.DeltaOld.d(), nD, 1, c1, x1, ctl, stream_);
     }
-    if (ty == 0 && any_pc) {                          // per-row weights rho_j(k) (:666-675)
+    if ((ty == 0 || ty == 2) && any_pc) {             // per-row weights rho_j(k) (:666-675, :805-811)
       RowMeanArgs ra;
       ra.n = n; ra.rows = ci.rows; ra.cols = (int)ci.cols;
       for (int j = 0; j < n; ++j) {
         ModeInfo& mi = modes_[ci.modes[j]];
         Par2Block* pb = pc_block(mi);
-        ra.fac[j] = mi.fac.d(); ra.mu[j] = mi.muD.d();
+        ra.fac[j] = image_f(mi.TF.d(), ci, mi.fac.d(), mi, ctl, stream_); ra.mu[j] = mi.muD.d();
         ra.rho[j] = pb ? pb->rhoc.d() : mi.rho.d();
         ra.vec[j] = pb ? 1 : 0;
       }
@@ -1394,6 +1463,16 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
         Coef cf[2] = {coef(1.0), coef(1.0)};
         const double* x[2] = {mi.fac.d(), mi.muD.d()};
         ew_lincomb(mi.tmp.d(), mi.rows * mi.R, 2, cf, x, ctl, stream_);
+        if (Par2Block* pb = pc_block(mi)) {           // rows weighted by rho_k: H'*diag(rho)*H and H'*diag(rho)*(C + mu)
+          pb->Hs.ensure((size_t)mi.hr * mi.hc * 8);
+          rows_scale(pb->Hs.d(), mi.H.d(), pb->rhoc.d(), mi.hr, mi.hc, ctl, stream_);
+          rows_scale(mi.tmp.d(), mi.tmp.d(), pb->rhoc.d(), mi.rows, mi.R, ctl, stream_);
+          gemm_small(ci.AA.d(), ci.rows, mi.Ht.d(), mi.hc, pb->Hs.d(), mi.hr, ci.rows, (int)mi.rows, (int)ci.rows, 0,
+                     coef(1.0), j == 0 ? 0.0 : 1.0, ctl, stream_);
+          gemm_small(ci.BB.d(), ci.rows, mi.Ht.d(), mi.hc, mi.tmp.d(), mi.rows, ci.rows, (int)mi.rows, mi.R, 0,
+                     coef(1.0), j == 0 ? 0.0 : 1.0, ctl, stream_);
+          continue;
+        }
         gemm_small(ci.AA.d(), ci.rows, mi.Ht.d(), mi.hc, mi.H.d(), mi.hr, ci.rows, (int)mi.rows, (int)ci.rows, 0,
                    coef(mi.rho.d(), 1.0), j == 0 ? 0.0 : 1.0, ctl, stream_);
         gemm_small(ci.BB.d(), ci.rows, mi.Ht.d(), mi.hc, mi.tmp.d(), mi.rows, ci.rows, (int)mi.rows, mi.R, 0,
@@ -1411,13 +1490,26 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
         const double* x[2] = {tf, mi.muD.d()};
         ew_lincomb(mi.tmp.d(), mi.img_rows * mi.img_cols, 2, cf, x, ctl, stream_);
         // BB += rho_j * (Tf(C_j) + mu_j) * H_j'   (:955 ; :1048 with H2 and rhoC)
-        if (ty == 4)
+        if (ty == 4 && pc_block(mi)) {                // rows weighted by rho_k (:955)
+          rows_scale(mi.tmp.d(), mi.tmp.d(), pc_block(mi)->rhoc.d(), mi.rows, mi.R, ctl, stream_);
+          gemm_small(ci.BB.d(), ci.rows, mi.tmp.d(), mi.rows, mi.H.d(), mi.hr, ci.rows, mi.R, (int)ci.cols, 1,
+                     coef(1.0), j == 0 ? 0.0 : 1.0, ctl, stream_);
+        } else if (ty == 4)
           gemm_small(ci.BB.d(), ci.rows, mi.tmp.d(), mi.rows, mi.H.d(), mi.hr, ci.rows, mi.R, (int)ci.cols, 1,
                      coef(mi.rho.d(), 1.0), j == 0 ? 0.0 : 1.0, ctl, stream_);
         else
           gemm_small(ci.BB.d(), ci.rows, mi.tmp.d(), mi.img_rows, mi.H2.d(), mi.h2r, ci.rows, mi.R, (int)ci.cols, 1,
                      coef(rho_last, 1.0), j == 0 ? 0.0 : 1.0, ctl, stream_);
       }
+      if (ty == 4 && any_pc) {                        // Delta(k,:) = BB(k,:) / (AA + rho_k*AAA)  (:957-961)
+        const Par2Block* pb = nullptr;
+        for (int j = 0; j < n; ++j)
+          if (Par2Block* q = pc_block(modes_[ci.modes[j]])) pb = q;
+        const int q = (int)ci.cols;
+        delta_rowwise_solve_k<<<(unsigned)ci.rows, 64, (size_t)(q * q + q) * sizeof(double), stream_>>>(
+            ci.Delta.d(), ci.BB.d(), ci.rows, q, ci.AA.d(), ci.LAA.d(), pb->rhoc.d(), ctl);
+        AO_KERNEL_CHECK();
+      } else
       row_solve(ci.Delta.d(), ci.rows, ci.BB.d(), ci.rows, ci.LAA.d(), ci.rows, (int)ci.cols, ctl, stream_);
     }
     {

@@ -242,3 +242,51 @@ def par2_C_coupled_model(rng, ctype, noise=0.0, K=16, I2=12, Jk=14):
             [lambda a, b: rng.standard_normal((a, b)), lambda a, b: rng.random((a, b)) + 0.1]
     io = dict(lambdas_init=[[1] * R, [1] * R], nvecs=0, distr=distr, normalize=1)
     return Z, io
+
+
+def par2_C_transformed_model(rng, ctype, noise=0.05, K=14, I2=10, Jk=12):
+    """CP first mode coupled to a PARAFAC2 C mode through a transformation of type 2 (C*H = Delta, shared columns),
+    3 (C = H*Delta, row sampling) or 4 (C = Delta*H, shared columns) -- cmtf_fun_AOADMM.m:300-366, :777-983."""
+    R6 = 3
+    if ctype == 3:
+        R1 = 3
+        D = rng.random((K, R6)) + 0.1
+        n1 = K // 2
+        sub = np.zeros((n1, K))
+        sub[np.arange(n1), 2 * np.arange(n1)] = 1.0
+        C6, C1 = D, sub @ D
+        H = [sub, None, None, None, None, np.eye(K)]
+    else:
+        R1 = 4
+        D = rng.random((K, R1)) + 0.1
+        n1 = K
+        C1, C6 = D, D[:, :R6]
+        sel = np.vstack([np.eye(R6), np.zeros((1, R6))])          # 4 x 3
+        if ctype == 2:                                             # C*H = Delta (K x 3)
+            H = [sel, None, None, None, None, np.eye(R6)]
+        else:                                                      # C = Delta*H, Delta is K x 4
+            H = [np.eye(R1), None, None, None, None, sel]
+    X1 = full_ktensor([C1, rng.random((13, R1)), rng.random((11, R1))])
+    A4 = rng.random((I2, R6))
+    DB = rng.standard_normal((R6, R6))
+    Xk = []
+    for k in range(K):
+        Q, _ = np.linalg.qr(rng.standard_normal((Jk, R6)))
+        Xk.append(A4 @ np.diag(C6[k]) @ (Q @ DB).T)
+    if noise > 0:
+        N = rng.standard_normal(X1.shape)
+        X1 = X1 + noise * np.linalg.norm(X1) / np.linalg.norm(N) * N
+        Xk = [x + noise * np.linalg.norm(x) / np.sqrt(x.size) * rng.standard_normal(x.shape) for x in Xk]
+    X1 /= np.linalg.norm(X1)
+    nrm = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in Xk))
+    Xk = [x / nrm for x in Xk]
+    Z = dict(loss_function=['Frobenius'] * 2, model=['CP', 'PAR2'], modes=[[1, 2, 3], [4, 5, 6]],
+             size=[n1, 13, 11, I2, [Jk] * K, K],
+             coupling=dict(lin_coupled_modes=[1, 0, 0, 0, 0, 1], coupling_type=[ctype], coupl_trafo_matrices=H),
+             constrained_modes=[1, 1, 0, 1, 0, 1],
+             constraints=[('non-negativity',), ('non-negativity',), None, ('non-negativity',), None, ('non-negativity',)],
+             weights=[0.5, 0.5], object=[X1, Xk])
+    distr = [lambda a, b: rng.random((a, b)) + 0.1] + [lambda a, b: rng.random((a, b))] * 3 + \
+            [lambda a, b: rng.standard_normal((a, b)), lambda a, b: rng.random((a, b)) + 0.1]
+    io = dict(lambdas_init=[[1] * R1, [1] * R6], nvecs=0, distr=distr, normalize=1)
+    return Z, io
