@@ -293,11 +293,11 @@ void Engine::model_end() {
     AO_REQUIRE(ci.modes.size() <= 8, "more than 8 modes in one coupling");
     for (int m : ci.modes)
       if (tensors_[modes_[m].tensor].par2 && modes_[m].pos == 2 && ci.type == 5)
-        throw Error(AOADMM_ERR_UNSUPPORTED, "coupling type 5 of a PARAFAC2 C mode is not in the device path (types 0-4 are; use the MATLAB path)");
-    if (ci.type == 4) {                       // :945-961 keeps one PARAFAC2 term apart (AAA); two would overwrite each other
+        AO_REQUIRE(modes_[m].hr <= modes_[m].rows, "coupling type 5 of a PARAFAC2 C mode: Delta has more rows than the mode (cmtf_fun_AOADMM.m:1049-1051 indexes rho by Delta's row)");
+    if (ci.type == 4 || ci.type == 5) {       // :945-961, :1034-1052 keep one PARAFAC2 term apart (AAA); two would overwrite each other
       int npc = 0;
       for (int m : ci.modes) npc += (tensors_[modes_[m].tensor].par2 && modes_[m].pos == 2) ? 1 : 0;
-      if (npc > 1) throw Error(AOADMM_ERR_UNSUPPORTED, "coupling type 4 with more than one PARAFAC2 C mode is not supported");
+      if (npc > 1) throw Error(AOADMM_ERR_UNSUPPORTED, fmt("coupling type %d with more than one PARAFAC2 C mode is not supported", ci.type));
     }
     const ModeInfo& m0 = modes_[ci.modes[0]];
     auto need_H = [&](int m) { AO_REQUIRE(modes_[m].hr > 0, "Coupling matrix for mode %d is missing.", m + 1); };
@@ -1344,7 +1344,7 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
     AO_HIP(hipStreamSynchronize(stream_));            // hp is a local
     ci.rho_ptrs_host = hp;
   }
-  const double* rho_last = hp[n - 1];                 // type 5: rhoC = mean(rho{mm}) with the stale loop variable (:1032)
+  const double* rho_last = modes_[ci.modes[n - 1]].rho.d();   // type 5: rhoC = mean(rho{mm}) with the stale loop variable (:1032)
   if (ty == 0 || ty == 1 || ty == 2) {
     coupling_coefs_k<<<1, 64, 0, stream_>>>(ci.coef.d(), rho_ptrs.as<const double*>(), n);
     AO_KERNEL_CHECK();
@@ -1353,7 +1353,7 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
     aa.n = 0; aa.Rc = (int)ci.cols; aaa.n = 0; aaa.Rc = (int)ci.cols;
     for (int j = 0; j < n; ++j) {
       const ModeInfo& mj = modes_[ci.modes[j]];
-      AAArgs& dst = (ty == 4 && pc_block(mj)) ? aaa : aa;
+      AAArgs& dst = pc_block(mj) ? aaa : aa;
       dst.H[dst.n] = ty == 4 ? mj.H.d() : mj.H2.d();
       dst.rho[dst.n] = (&dst == &aaa) ? ones_.d() : (ty == 4 ? hp[j] : rho_last);
       dst.R[dst.n] = mj.R;
@@ -1376,7 +1376,7 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
       const double* TD = (it == 0 || ty == 0 || ty == 1 || ty == 2) ? image_d(mi.TD.d(), ci, ci.Delta.d(), mi, ctl, stream_)
                                                                      : mi.TD.d();
       Par2Block* pb = pc_block(mi);
-      if (pb && ty != 1) {
+      if (pb && ty != 1 && ty != 5) {
         // row k: A_inner = a_k + rho_k/2*Tf'(Sd(Delta) - mu_Delta)(k,:) [+ rho_k/2*(Z - mu)(k,:)], solved with L_k
         // (:638-645, :785-792, :850-857, :916-923); Tf' is the identity except for type 2 (right-multiplication by H')
         if (ty == 2) {
@@ -1408,7 +1408,7 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
         const double* x[4] = {mi.Aeff, adj, mi.Z.d(), mi.mu.d()};
         ew_lincomb(mi.RHS.d(), nm, mi.constrained ? 4 : 2, cf, x, ctl, stream_);
       }
-      if (pb && ty == 1) {
+      if (pb && (ty == 1 || ty == 5)) {
         // vec(C') = (blkdiag(B_k) + rhoC/2*kron(H'H,I) [+ rhoC/2*I]) \ vec(A_inner') (:714-722); mi.rho holds rhoC
         dense_symv_rows(pb->Minv.d(), mi.RHS.d(), mi.fac.d(), pb->K, pb->R, ctl, stream_);
       } else if (ty == 1 || ty == 5) {
@@ -1501,7 +1501,7 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
           gemm_small(ci.BB.d(), ci.rows, mi.tmp.d(), mi.img_rows, mi.H2.d(), mi.h2r, ci.rows, mi.R, (int)ci.cols, 1,
                      coef(rho_last, 1.0), j == 0 ? 0.0 : 1.0, ctl, stream_);
       }
-      if (ty == 4 && any_pc) {                        // Delta(k,:) = BB(k,:) / (AA + rho_k*AAA)  (:957-961)
+      if (any_pc) {                                   // Delta(k,:) = BB(k,:) / (AA + rho_k*AAA)  (:957-961, :1049-1052)
         const Par2Block* pb = nullptr;
         for (int j = 0; j < n; ++j)
           if (Par2Block* q = pc_block(modes_[ci.modes[j]])) pb = q;

@@ -244,7 +244,7 @@ void Engine::par2_update_C(int m, const aoadmm_options& opt) {
 // mode C inside a coupling (:253-385): right-hand sides a_k, rho_k and the systems the coupled ADMM needs --
 // types 0, 3, 4: per-row Cholesky factors of w*C_k + rho_k/2*I (+ rho_k/2*I if constrained) (:260-267, :327-334, :349-356);
 // type 2: the same with rho_k/2*H*H' for the coupling term (:305-312);
-// type 1: the (K*R) x (K*R) system blkdiag(w*C_k) + rhoC/2*kron(H'H, I) (+ rhoC/2*I), rhoC = mean(rho) (:282-297)
+// types 1, 5: the (K*R) x (K*R) system blkdiag(w*C_k) + rhoC/2*kron(H'H, I) (+ rhoC/2*I), rhoC = mean(rho) (:282-297, :371-385)
 void Engine::par2_prepare_C_coupled(int m, int ctype, const aoadmm_options& opt) {
   ModeInfo& mi = modes_[m];
   TensorInfo& t = tensors_[mi.tensor];
@@ -254,19 +254,20 @@ void Engine::par2_prepare_C_coupled(int m, int ctype, const aoadmm_options& opt)
   ModeInfo& mB = modes_[t.modes[1]];
   AdmmCtl* ctl = ctl_of_mode(m);
   const int con = mi.constrained ? 1 : 0;
+  const bool big = ctype == 1 || ctype == 5;          // H*C = ...: one (K*R) x (K*R) system instead of K row systems
   b.rhosum.ensure(64);
   par2_xkb(b.X.d(), mB.fac.d(), d, b.T1.d(), stream_);
   par2_c_system(mA.fac.d(), b.T1.d(), mA.gram.d(), b.GB.d(), t.weight, has_ridge_ ? mi.ridge : 0.0,
-                opt.bsum ? opt.bsum_weight / 2 : 0.0, ctype == 1 ? 0 : (ctype == 2 ? con : 1 + con), ctype == 1 ? 1 : 0, d,
+                opt.bsum ? opt.bsum_weight / 2 : 0.0, big ? 0 : (ctype == 2 ? con : 1 + con), big ? 1 : 0, d,
                 mi.fac.d(), b.ac.d(), b.rhoc.d(), b.Lc.d(), ctl, stream_, ctype == 2 ? mi.HHt.d() : nullptr);
   // max(rho) for the prox (:1424); mean(rho) takes the place of the scalar rho of a CP mode (:284, :712), sum(rho)
   // weighs this mode in the Delta update (:736)
   par2_rho_max(b.rhoc.d(), b.K, b.rhomax.d(), stream_, mi.rho.d(), b.rhosum.d());
   t.last_pos = 2;                                                              // last_m(p) = 3
   mi.Aeff = b.ac.d();
-  if (ctype == 1) {
+  if (big) {
     const int n = b.K * b.R;
-    AO_REQUIRE(n <= kDenseMaxN, "PARAFAC2 C mode coupled with type 1: K*R = %d exceeds the dense-system limit %d", n, kDenseMaxN);
+    AO_REQUIRE(n <= kDenseMaxN, "PARAFAC2 C mode coupled with type %d: K*R = %d exceeds the dense-system limit %d", ctype, n, kDenseMaxN);
     AO_REQUIRE(mi.hc == b.K, "coupling matrix of the PARAFAC2 C mode has %lld columns, the mode has %d rows", (long long)mi.hc, b.K);
     if (!b.have_HtH) {
       b.HtH.ensure((size_t)b.K * b.K * 8);

@@ -12,8 +12,7 @@ function [G,out] = cmtf_fun_AOADMM_hip(Z,Znorm_const,G,fh,gh,lscalar,uscalar,opt
 %
 % Function handles cannot cross to the GPU, so Z.prox_operators / Z.reg_func (cmtf_AOADMM.m:30-32) are
 % dropped and the MEX gateway re-reads the constraint descriptors Z.constraints{m}. Models the device
-% path does not cover ('custom' constraints, KL/IS/beta losses, sptensor data, coupling type 5 of a
-% PARAFAC2 C mode) raise cmtf:hip:unsupported, which is caught here and
+% path does not cover ('custom' constraints, KL/IS/beta losses, sptensor data) raise cmtf:hip:unsupported, which is caught here and
 % handed to the original MATLAB implementation, so every example script keeps running.
 % Znorm_const, fh, gh, lscalar, uscalar are only needed by that fallback.
 

@@ -10,7 +10,7 @@ relative to /root/reference/):
     `functions/cp_func.m`, `functions/pca_func.m`
 
 Scope: Frobenius loss; CP blocks (tensors and matrices) and PARAFAC2 blocks;
-coupling types 0-5 for CP modes (types 0 and 4 also for the PARAFAC2 C mode);
+coupling types 0-5 for CP modes and for the PARAFAC2 C mode;
 every constraint of `constraints_to_prox.m`.  Out of scope (raises):
 KL/IS/beta losses (need the external L-BFGS-B MEX).
 
@@ -279,18 +279,17 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
                 D = G['coupling_fac'][cid]
                 muD = G['coupling_dual_fac'][mm]
                 H = ctm[mm]
-                if is_par2_C(mm) and ctype == 1:                                   # :710-724
-                    # one (K*R) x (K*R) system for vec(C') with the common rhoC = mean(rho) (:712)
+                if is_par2_C(mm) and ctype in (1, 5):                              # :710-724, :998-1010
+                    # one (K*R) x (K*R) system for vec(C') with the common rhoC = mean(rho) (:712, :1000)
                     rhoC = float(np.mean(rho[mm]))
                     A_large = np.concatenate([np.ravel(A[mm][kk]) for kk in range(_K_of(Z, pp))])       # :714-716
-                    A_inner = A_large + rhoC / 2 * np.ravel(H.T @ (D - muD))       # HcI'*vec((D-mu)') = vec((H'(D-mu))')  (:717)
+                    img = D if ctype == 1 else D @ ctm2[mm]                        # :717 / :1005 (Delta*H2)
+                    A_inner = A_large + rhoC / 2 * np.ravel(H.T @ (img - muD))     # HcI'*vec(Y') = vec((H'Y)')
                     if constrained[mm]:
                         A_inner = A_inner + rhoC / 2 * np.ravel(G['constraint_fac'][mm] - G['constraint_dual_fac'][mm])   # :719
                     x = sla.cho_solve((L[mm], True), A_inner)                        # :721
                     G['fac'][mm] = x.reshape(G['fac'][mm].shape)                     # :722 (vec of C' = rows of C back to back)
                 elif is_par2_C(mm):
-                    if ctype not in (0, 2, 3, 4):
-                        raise NotImplementedError('PAR2 C-mode coupling type 5 (kron system) not restated')
                     for kk in range(_K_of(Z, pp)):
                         r2 = rho[mm][kk] / 2
                         if ctype == 0:                                             # :640
@@ -385,11 +384,22 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
                 AA = np.zeros((H2_1.shape[0], H2_1.shape[0]))
                 BB = np.zeros((ctm[cmodes[0]].shape[0], H2_1.shape[0]))
                 mm_last = cmodes[-1]           # QUIRK :1032 -- rhoC uses the loop variable `mm` left over
+                par2 = None
                 for jj in cmodes:
                     rhoC = float(np.mean(rho[mm_last]))
-                    AA = AA + rhoC * (ctm2[jj] @ ctm2[jj].T)
+                    if is_par2_C(jj):                                              # :1034-1040
+                        par2 = jj
+                        AAA = ctm2[jj] @ ctm2[jj].T
+                    else:
+                        AA = AA + rhoC * (ctm2[jj] @ ctm2[jj].T)
                     BB = BB + rhoC * (ctm[jj] @ G['fac'][jj] + G['coupling_dual_fac'][jj]) @ ctm2[jj].T
-                G['coupling_fac'][cid] = _mrdivide(BB, AA)
+                if par2 is not None:                                               # :1049-1052 (rho_k indexed by Delta's row)
+                    newD = np.array(G['coupling_fac'][cid], copy=True)
+                    for kk in range(newD.shape[0]):
+                        newD[kk, :] = _mrdivide(BB[kk:kk + 1, :], AA + rho[par2][kk] * AAA)[0]
+                    G['coupling_fac'][cid] = newD
+                else:
+                    G['coupling_fac'][cid] = _mrdivide(BB, AA)
             # ---- dual + constraint updates
             D = G['coupling_fac'][cid]
             for mm in cmodes:
@@ -728,7 +738,7 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
                 ctype = int(Z['coupling']['coupling_type'][coupl_id - 1])
                 for m in coupled_modes:
                     R_ = None
-                    if is_par2_C(m) and ctype == 1:                            # :282-297
+                    if is_par2_C(m) and ctype in (1, 5):                       # :282-297, :371-385
                         Kc = _K_of(Z, which_p[m])
                         R_ = B[m][0].shape[0]
                         HcI = np.kron(ctm[m], np.eye(R_))                                          # :283
@@ -738,8 +748,6 @@ def cmtf_fun_AOADMM(Z, Znorm_const, G, options, trace=None):
                             B2[m] = B2[m] + float(np.mean(rho[m])) / 2 * np.eye(B2[m].shape[0])    # :292
                         L[m] = np.linalg.cholesky(B2[m])                                           # :296
                     elif is_par2_C(m):
-                        if ctype == 5:
-                            raise NotImplementedError('PAR2 C-mode coupling type 5 not restated')
                         for k in range(_K_of(Z, which_p[m])):
                             R_ = B[m][k].shape[0]
                             if ctype == 2:

@@ -246,7 +246,8 @@ def par2_C_coupled_model(rng, ctype, noise=0.0, K=16, I2=12, Jk=14):
 
 def par2_C_transformed_model(rng, ctype, noise=0.05, K=14, I2=10, Jk=12):
     """CP first mode coupled to a PARAFAC2 C mode through a transformation of type 2 (C*H = Delta, shared columns),
-    3 (C = H*Delta, row sampling) or 4 (C = Delta*H, shared columns) -- cmtf_fun_AOADMM.m:300-366, :777-983."""
+    3 (C = H*Delta, row sampling), 4 (C = Delta*H, shared columns) or 5 (H*C = Delta*H2, both) --
+    cmtf_fun_AOADMM.m:300-385, :777-1075."""
     R6 = 3
     if ctype == 3:
         R1 = 3
@@ -256,6 +257,15 @@ def par2_C_transformed_model(rng, ctype, noise=0.05, K=14, I2=10, Jk=12):
         sub[np.arange(n1), 2 * np.arange(n1)] = 1.0
         C6, C1 = D, sub @ D
         H = [sub, None, None, None, None, np.eye(K)]
+    elif ctype == 5:                                               # H*C = Delta*H2 (example_script13 relations)
+        R1 = 4
+        D = rng.random((K, R1)) + 0.1
+        n1 = K // 2
+        sub = np.zeros((n1, K))
+        sub[np.arange(n1), 2 * np.arange(n1)] = 1.0
+        C6, C1 = D[:, :R6], sub @ D                                # Delta = sub*D (n1 x 4): C1 = Delta, sub*C6 = Delta(:,1:3)
+        H = [np.eye(n1), None, None, None, None, sub]
+        H2 = [np.eye(R1), None, None, None, None, np.vstack([np.eye(R6), np.zeros((1, R6))])]
     else:
         R1 = 4
         D = rng.random((K, R1)) + 0.1
@@ -282,7 +292,8 @@ def par2_C_transformed_model(rng, ctype, noise=0.05, K=14, I2=10, Jk=12):
     Xk = [x / nrm for x in Xk]
     Z = dict(loss_function=['Frobenius'] * 2, model=['CP', 'PAR2'], modes=[[1, 2, 3], [4, 5, 6]],
              size=[n1, 13, 11, I2, [Jk] * K, K],
-             coupling=dict(lin_coupled_modes=[1, 0, 0, 0, 0, 1], coupling_type=[ctype], coupl_trafo_matrices=H),
+             coupling=dict(lin_coupled_modes=[1, 0, 0, 0, 0, 1], coupling_type=[ctype], coupl_trafo_matrices=H,
+                           **({'coupl_trafo_matrices2': H2} if ctype == 5 else {})),
              constrained_modes=[1, 1, 0, 1, 0, 1],
              constraints=[('non-negativity',), ('non-negativity',), None, ('non-negativity',), None, ('non-negativity',)],
              weights=[0.5, 0.5], object=[X1, Xk])

@@ -128,13 +128,13 @@ def draw_transformed(seed):
     rng = np.random.default_rng(seed)
     if seed >= 3000 and seed % 2 == 1:
         from helpers import par2_C_transformed_model
-        ctype = int(rng.choice([2, 3, 4]))
+        ctype = int(rng.choice([2, 3, 4, 5]))
         K = int(rng.integers(3, 9)) * 2
         Z, io = par2_C_transformed_model(rng, ctype, K=K, I2=int(rng.integers(6, 14)), Jk=int(rng.integers(6, 15)))
         if rng.random() < 0.4:
             Z['constrained_modes'][5] = 0
             Z['constraints'][5] = None
-        Delta = [np.zeros((K, 4))] if ctype == 4 else None
+        Delta = [np.zeros((K, 4))] if ctype == 4 else ([np.zeros((K // 2, 4))] if ctype == 5 else None)
         opt = options(MaxOuterIters=int(rng.integers(4, 9)), MaxInnerIters=int(rng.integers(3, 7)))
         return Z, io, opt, Delta
     if seed >= 3000:

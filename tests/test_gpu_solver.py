@@ -314,30 +314,17 @@ def test_parafac2_C_mode_coupling(pkg, eng, ctype, constr6):
     compare_par2(*run_both(pkg, eng, Z, io, options(MaxOuterIters=12)))
 
 
-@pytest.mark.parametrize('ctype', [2, 3, 4])
+@pytest.mark.parametrize('ctype', [2, 3, 4, 5])
 def test_parafac2_C_mode_transformed_coupling(pkg, eng, ctype):
     """A PARAFAC2 C mode in couplings of type 2 (C*H = Delta: + rho_k/2*H*H' in the row systems, :305-312, :785-792),
-    3 (C = H*Delta: Delta from H'*diag(rho)*H, :327-334, :875-885) and 4 (C = Delta*H: one q x q system per row of
-    Delta, AA + rho_k*AAA, :349-356, :945-961)."""
+    3 (C = H*Delta: Delta from H'*diag(rho)*H, :327-334, :875-885), 4 (C = Delta*H: one q x q system per row of
+    Delta, AA + rho_k*AAA, :349-356, :945-961) and 5 (H*C = Delta*H2: the (K*R)^2 system of type 1 for C, the per-row
+    systems of type 4 for Delta, :371-385, :998-1052)."""
     from helpers import par2_C_transformed_model
     rng = np.random.default_rng(170 + ctype)
     Z, io = par2_C_transformed_model(rng, ctype)
-    Delta = [np.zeros((14, 4))] if ctype == 4 else None
+    Delta = [np.zeros((14, 4))] if ctype == 4 else ([np.zeros((7, 4))] if ctype == 5 else None)
     compare_par2(*run_both(pkg, eng, Z, io, options(MaxOuterIters=12), Delta=Delta))
-
-
-def test_parafac2_C_mode_coupling_type5_unsupported(pkg, eng):
-    """Type 5 on a PARAFAC2 C mode is not in the device path: the engine must say so, not compute something else."""
-    from helpers import par2_C_coupled_model
-    capi = __import__('importlib').import_module('matlab-code_amd._capi')
-    rng = np.random.default_rng(160)
-    Z, io = par2_C_coupled_model(rng, 1)
-    Z['coupling']['coupling_type'] = [5]
-    Z['coupling']['coupl_trafo_matrices2'] = [np.eye(3), None, None, None, None, np.eye(3)]
-    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None, 'coupling': dict(Z['coupling'], coupling_type=[1])}, io,
-                                    rng=np.random.default_rng(7))
-    with pytest.raises(capi.UnsupportedOnDevice):
-        pkg.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=2), init=copy.deepcopy(G), engine=eng)
 
 
 def test_display_iter_reports_live(pkg, eng, capsys):
