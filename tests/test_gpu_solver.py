@@ -343,3 +343,36 @@ def test_display_iter_reports_live(pkg, eng, capsys):
         it = int(r[0])
         assert abs(float(r[2]) - out['func_val_conv'][it]) < 5e-7       # printed with 6 decimals
         assert abs(float(r[4]) - out['func_constr_conv'][it]) < 5e-7
+
+
+@pytest.mark.parametrize('family', ['cp_tv_f32', 'script1_par2', 'script3_coupled'])
+def test_run_to_run_bitwise_reproducible(pkg, eng, family):
+    """Every reduction in the library has a fixed summation order (block partials added in order, no floating-point
+    atomics), so two solves from the same struct must agree bit for bit -- the determinism SURVEY section 5 asks for."""
+    from helpers import script1_model
+    rng = np.random.default_rng(77)
+    prec = 'f64'
+    if family == 'cp_tv_f32':
+        Z, io, _ = cp_model((131, 37, 29), 5, rng, [('TV regularization', 0.01), ('non-negativity',), ('simplex column-wise', 1.0)])
+        prec = 'f32'
+    elif family == 'script1_par2':
+        Z, io = script1_model(rng, dims=(20, 30, 40))
+    else:
+        Z, io = script3_model(rng)
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(7))
+    runs = []
+    for _ in range(2):
+        _, F, _, o = pkg.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=8), init=copy.deepcopy(G), engine=eng, precision=prec)
+        runs.append((F, o))
+
+    def same(a, b):
+        if a is None:
+            return True
+        if isinstance(a, (list, tuple)):
+            return all(same(x, y) for x, y in zip(a, b))
+        if isinstance(a, dict):
+            return all(same(a[k], b[k]) for k in a)
+        return np.array_equal(a, b)
+    for key in ('fac', 'constraint_fac', 'constraint_dual_fac', 'coupling_fac', 'coupling_dual_fac'):
+        assert same(runs[0][0][key], runs[1][0][key]), key
+    assert np.array_equal(runs[0][1]['func_val_conv'], runs[1][1]['func_val_conv'])
