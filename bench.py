@@ -192,7 +192,8 @@ def main():
                                    'MaxInnerIters=5, tol=0' % (I, J, K, R, args.prec),
                        'sharding': 'mode-1 rows over %d GPU(s), factors replicated' % world,
                        'tensor_passes_per_iter': round((launches + int(nl1.value)) / args.steps, 2),
-                       'resident_copies': 'X(i,j,k) + mode-permuted X(j,k,i): 2 x %.0f GB per node'
+                       'resident_copies': 'X(i,j,k) + mode-permuted X(j,k,i) and X(k,i,j): 3 x %.0f GB per node, '
+                                          'every pass contracts a trailing mode'
                                           % (I * J * K * (4.0 if args.prec == 'f32' else 8.0) / 1e9)},
             'mttkrp_mode1_gflops': flops_mttkrp / (mttkrp_ms * 1e-3) / 1e9,
             'mttkrp_mode1_ms': mttkrp_ms,

@@ -111,9 +111,9 @@ typedef struct aoadmm_options {
   double increase_factor_rhoBk;
   int32_t use_dimtree;                   /* engine option (options.hip.*): reuse partial
                                             contractions between modes; 1 = default */
-  int32_t no_permuted_copy;              /* engine option: 1 = do not keep the second, mode-permuted resident copy of
-                                            3-way tensors (saves the tensor's size in HBM, mode-1 contractions then
-                                            use the LDS-transposed kernel); 0 = default */
+  int32_t no_permuted_copy;              /* engine option: 1 = do not keep the two mode-permuted resident copies of
+                                            3-way tensors (saves twice the tensor's size in HBM; mode-1 contractions then
+                                            use the LDS-transposed kernel, mode-2 ones run batched); 0 = default */
   int32_t par2_slab_sharding;            /* engine option, with a communicator: 0 = auto (a PARAFAC2 block is repeated
                                             on every rank unless it has >= 1024 slabs per rank), 1 = shard the slabs
                                             over the ranks, -1 = never.  Blocks with Z.miss or the tPARAFAC2 constraint

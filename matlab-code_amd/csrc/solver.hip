@@ -455,8 +455,8 @@ void Engine::block_upload(CpBlock& b, int nd, const int64_t* dims, const double*
   }
   b.has_data = true;
   b.cached_mode = -1;
-  b.has_xp = false; b.xp_refused = false;
-  if (nd == 3) (void)ensure_permuted_copy(b);        // one-off set-up cost belongs to the upload, not to the first solve
+  b.has_xp = false; b.xp_refused = false; b.has_xq = false; b.xq_refused = false;
+  if (nd == 3) (void)ensure_permuted_copy2(b);       // one-off set-up cost belongs to the upload, not to the first solve
 }
 
 void Engine::tensor_upload(int p, const double* data, int prec, int64_t row0, int64_t local_rows) {
@@ -561,8 +561,8 @@ void Engine::tensor_synth(int p, int rank, uint64_t seed, double noise, int prec
   AO_HIP(hipStreamSynchronize(stream_));
   b.has_data = true;
   b.cached_mode = -1;
-  b.has_xp = false; b.xp_refused = false;
-  (void)ensure_permuted_copy(b);                     // set-up cost of the data, like the generation itself
+  b.has_xp = false; b.xp_refused = false; b.has_xq = false; b.xq_refused = false;
+  (void)ensure_permuted_copy2(b);                    // set-up cost of the data, like the generation itself
   AO_HIP(hipStreamSynchronize(stream_));
   t.normsq_valid = false;
 }
@@ -596,7 +596,7 @@ void Engine::tensor_mask_upload(int p, const uint8_t* mask) {
   }
   AO_HIP(hipStreamSynchronize(stream_));
   b.has_mask = true;
-  if (b.has_xp) { b.Xp.release(); b.has_xp = false; b.cached_mode = -1; }    // the imputation would have to update it too
+  drop_permuted_copies(b);                           // the imputation would have to update them too
   t.normsq_valid = false;
 }
 
@@ -864,6 +864,29 @@ bool Engine::ensure_permuted_copy(CpBlock& b) {
   return true;
 }
 
+// Xq(k,i,j) = X(i,j,k), built from Xp(j,k,i) by the same 231 permutation
+bool Engine::ensure_permuted_copy2(CpBlock& b) {
+  if (b.has_xq) return true;
+  if (b.xq_refused || !ensure_permuted_copy(b)) return false;
+  const int64_t I = b.dims[0], J = b.dims[1], K = b.dims[2];
+  const int64_t Kp = round_up(K, b.X.prec == AOADMM_PREC_F32 ? 4 : 2);
+  const size_t bytes = (size_t)Kp * I * J * b.X.elem_size();
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (size_t)(4ull << 30) || I > 65535) {
+    b.xq_refused = true;
+    return false;
+  }
+  b.Xq.alloc(bytes);
+  b.Kp = Kp;
+  permute_231(b.Xp.p, b.Xq.p, b.X.prec, J, b.Jp, K, Kp, I, stream_);
+  b.has_xq = true;
+  return true;
+}
+void Engine::drop_permuted_copies(CpBlock& b) {
+  if (b.has_xp) { b.Xp.release(); b.has_xp = false; b.cached_mode = -1; }
+  if (b.has_xq) { b.Xq.release(); b.has_xq = false; b.cached_mode = -1; }
+}
+
 void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int R, bool use_cache,
                                 const int* update_seq, int nseq) {
   const int prec = b.X.prec;
@@ -887,8 +910,15 @@ void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int 
   ContractPlan pl;
   const double* Fc = facs[c].p;
   if (c == 2) pl = make_plan(1, 0, Ip * J, Ip * J, K, R, prec);
-  else if (c == 1) pl = make_plan(K, Ip * J, Ip, Ip, J, R, prec);
-  else {
+  else if (c == 1) {
+    if (use_cache && ensure_permuted_copy2(b)) {
+      // Xq(k,i,j): mode 2 is the trailing index with stride Kp*I -> one streaming pass instead of K batches
+      pl = make_plan(1, 0, b.Kp * I, b.Kp * I, J, R, prec);
+      pl.on_xq = true;
+    } else {
+      pl = make_plan(K, Ip * J, Ip, Ip, J, R, prec);
+    }
+  } else {
     Fc = facs[0].p + (sharded() ? b.row0 : 0);
     static const bool force_ldskernel = getenv("AOADMM_LEAD_KERNEL") != nullptr;   // development switch
     if (!force_ldskernel && ensure_permuted_copy(b)) {
@@ -900,7 +930,7 @@ void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int 
     }
   }
   b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
-  timed_contract(pl.on_xp ? b.Xp.p : b.X.data.p, prec, pl, Fc, facs[c].ld, b.frag.p, b.T.p);
+  timed_contract(pl.on_xp ? b.Xp.p : (pl.on_xq ? b.Xq.p : b.X.data.p), prec, pl, Fc, facs[c].ld, b.frag.p, b.T.p);
   b.cached_mode = c; b.cached_version = facs[c].version; b.plan = pl;
 }
 
@@ -964,22 +994,29 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
     ensure_contraction(b, pos, facs, R, use_cache, update_seq, nseq);
     const int c = b.cached_mode;
     const ContractPlan& pl = b.plan;
-    // T rows are (a + Apad*bb) with (a, bb) the two uncontracted modes in tensor order
-    const int ia = c == 0 ? 1 : 0, ib = c == 2 ? 1 : 2;
-    const int64_t An = ia == 0 ? I : J, Apad = ia == 0 ? Ip : (pl.on_xp ? b.Jp : J);
-    const int64_t Bn = ib == 1 ? J : K;
-    const double* Fa = ia == 0 ? F0 : facs[1].p;
+    // T rows are (a + Apad*bb) with (a, bb) the two uncontracted modes in the order the pass's copy stores them:
+    // tensor order on X and Xp, (k, i) on Xq
+    int ia = c == 0 ? 1 : 0, ib = c == 2 ? 1 : 2;
+    if (pl.on_xq) { ia = 2; ib = 0; }
+    const int64_t ext[3] = {I, J, K};
+    const int64_t An = ext[ia], Bn = ext[ib];
+    const int64_t Apad = pl.on_xq ? b.Kp : (ia == 0 ? Ip : (pl.on_xp ? b.Jp : J));
+    // factor of a mode: the first mode's factor is addressed at this rank's rows
+    auto fac_p = [&](int m) { return m == 0 ? F0 : facs[m].p; };
+    auto fac_pT = [&](int m) -> const double* {
+      if (!facs[m].pT) return nullptr;
+      return facs[m].pT + ((m == 0 && sharded) ? b.row0 * R : 0);
+    };
     if (pos == ia) {
       b.scratch.ensure(reduce_outer_scratch_bytes(An, Bn, R));
       b.ft.ensure(reduce_factor_scratch_bytes(Bn, R));
-      launch_reduce_outer(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, facs[ib].p, facs[ib].ld, scale,
-                          out_local, ldOut, b.scratch.d(), b.ft.d(), stream_, facs[ib].pT);
+      launch_reduce_outer(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, fac_p(ib), facs[ib].ld, scale,
+                          out_local, ldOut, b.scratch.d(), b.ft.d(), stream_, fac_pT(ib));
     } else {
       AO_REQUIRE(pos == ib, "internal: cached contraction cannot serve this mode");
       b.ft.ensure(reduce_factor_scratch_bytes(An, R));
-      const double* FaT = facs[ia].pT ? facs[ia].pT + ((ia == 0 && sharded) ? b.row0 * R : 0) : nullptr;
-      launch_reduce_inner(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, Fa, facs[ia].ld, scale, out_local,
-                          ldOut, b.ft.d(), stream_, FaT);
+      launch_reduce_inner(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, fac_p(ia), facs[ia].ld, scale, out_local,
+                          ldOut, b.ft.d(), stream_, fac_pT(ia));
     }
   } else {
     // N-way (N > 3): contract the last mode (the one before it when pos is last) on the matrix cores with all
@@ -1664,7 +1701,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   allow_xp_ = opt.no_permuted_copy == 0;
   if (!allow_xp_)
     for (int p = 0; p < n_tensors_; ++p)
-      if (tensors_[p].blk.has_xp) { tensors_[p].blk.Xp.release(); tensors_[p].blk.has_xp = false; tensors_[p].blk.cached_mode = -1; }
+      drop_permuted_copies(tensors_[p].blk);
   for (int p = 0; p < n_tensors_; ++p) {
     AO_REQUIRE(tensors_[p].blk.has_data, "tensor %d has no data (Z.object{%d})", p, p + 1);
   }
