@@ -69,6 +69,9 @@ void par2_c_system(const double* A, const double* T1, const double* GA, const do
 void par2_rho_max(const double* rho, int K, double* rhomax, hipStream_t s, double* rhomean = nullptr,
                   double* rhosum = nullptr);
 // (K*R) x (K*R) system of a C mode coupled through H*C = Delta (:283-293); HtH = H'*H (K x K), rhoC = mean(rho) on the device
+// the same system when H'H = diag(d): K independent row systems, L (holding B_k) is overwritten by chol(B_k + rhoC/2*(d_k [+1])*I)
+void par2_c_rowsys_diag(double* L, const double* d, const double* rhoC, int constrained, int K, int R, AdmmCtl* ctl,
+                        hipStream_t s);
 void par2_c_big_system(const double* Bk, const double* HtH, const double* rhoC, int constrained, int K, int R, double* M,
                        hipStream_t s);
 // row k: rhs = a_k (+ rho_k/2 (Z(k,:) - mu(k,:))) ; C(k,:) = L_k'\(L_k\rhs)      (:236, :604-605)

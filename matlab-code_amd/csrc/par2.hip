@@ -597,6 +597,23 @@ __global__ void par2_c_big_system_k(const double* Bk, const double* HtH, const d
     M[e] = m;
   }
 }
+// diagonal H'H: L_k = chol(B_k + rhoC/2*(d_k + constrained)*I), in place over B_k
+__global__ void par2_c_rowsys_diag_k(double* L, const double* d, const double* rhoC, int constrained, int R, AdmmCtl* ctl) {
+  extern __shared__ double sh[];
+  const int k = blockIdx.x;
+  const double add = rhoC[0] / 2 * (d[k] + (constrained ? 1.0 : 0.0));
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) sh[e] = L[(int64_t)k * R * R + e] + ((e % R == e / R) ? add : 0.0);
+  __syncthreads();
+  const bool ok = chol_lds(sh, R);
+  if (ok)
+    for (int e = threadIdx.x; e < R * R; e += blockDim.x) L[(int64_t)k * R * R + e] = sh[e];
+  else if (threadIdx.x == 0 && ctl) ctl->notpd = 1;
+}
+void par2_c_rowsys_diag(double* L, const double* d, const double* rhoC, int constrained, int K, int R, AdmmCtl* ctl,
+                        hipStream_t s) {
+  par2_c_rowsys_diag_k<<<K, kP2Threads, (size_t)R * R * sizeof(double), s>>>(L, d, rhoC, constrained, R, ctl);
+  AO_KERNEL_CHECK();
+}
 void par2_c_big_system(const double* Bk, const double* HtH, const double* rhoC, int constrained, int K, int R, double* M,
                        hipStream_t s) {
   const int64_t n2 = (int64_t)K * R * K * R;

@@ -107,7 +107,7 @@ struct Par2Block {
   DevBuf psum;                    // R*R+1 partial sums of DeltaB, then 4 residual means
   // coupled C mode: sum(rho_k); H'H, the (K*R)^2 system and its inverse for coupling type 1 (:282-297)
   DevBuf rhosum, HtH, Mbig, Minv, Hs;   // Hs = diag(rho)*H for coupling type 3
-  bool have_HtH = false;
+  bool have_HtH = false, hth_diag = false;   // hth_diag: H'H is diagonal, HtH holds its K diagonal entries
   P2Dims dims() const {
     P2Dims d;
     d.K = K; d.I = I; d.R = R; d.off = off_d.as<int64_t>(); d.off_h = off_h.data(); d.Jtot = Jtot; d.Jmax = Jmax;

@@ -1447,7 +1447,10 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
       }
       if (pb && (ty == 1 || ty == 5)) {
         // vec(C') = (blkdiag(B_k) + rhoC/2*kron(H'H,I) [+ rhoC/2*I]) \ vec(A_inner') (:714-722); mi.rho holds rhoC
-        dense_symv_rows(pb->Minv.d(), mi.RHS.d(), mi.fac.d(), pb->K, pb->R, ctl, stream_);
+        if (pb->hth_diag)                             // H'H diagonal: the system is K row systems (solver_par2.hip)
+          par2_c_rowsolve(mi.RHS.d(), pb->rhoc.d(), pb->Lc.d(), nullptr, nullptr, 0, pb->dims_all(), mi.fac.d(), ctl, stream_);
+        else
+          dense_symv_rows(pb->Minv.d(), mi.RHS.d(), mi.fac.d(), pb->K, pb->R, ctl, stream_);
       } else if (ty == 1 || ty == 5) {
         // sylvester(B2, B, A_inner) (:707, :1016) with B2 = rho/2*H'H (+ rho/2*I if constrained) = U (..) U',
         // B = V diag(mu) V':  X = U * ((U' A_inner V) ./ (beta_i + mu_j)) * V'

@@ -267,16 +267,42 @@ void Engine::par2_prepare_C_coupled(int m, int ctype, const aoadmm_options& opt)
   mi.Aeff = b.ac.d();
   if (big) {
     const int n = b.K * b.R;
-    AO_REQUIRE(n <= kDenseMaxN, "PARAFAC2 C mode coupled with type %d: K*R = %d exceeds the dense-system limit %d", ctype, n, kDenseMaxN);
     AO_REQUIRE(mi.hc == b.K, "coupling matrix of the PARAFAC2 C mode has %lld columns, the mode has %d rows", (long long)mi.hc, b.K);
     if (!b.have_HtH) {
-      b.HtH.ensure((size_t)b.K * b.K * 8);
-      gemm_small(b.HtH.d(), b.K, mi.Ht.d(), mi.hc, mi.H.d(), mi.hr, b.K, (int)mi.hr, b.K, 0, coef(1.0), 0.0, nullptr, stream_);
+      // H'H once per model, on the host: when it is diagonal (H selects or scales rows -- every sampling-rate
+      // coupling, script 14) kron(H'H, I) is diagonal too and the (K*R)-system falls apart into K row systems
+      const int64_t hr = mi.hr;
+      std::vector<double> hth((size_t)b.K * b.K, 0.0);
+      bool diag = true;
+      for (int a = 0; a < b.K; ++a)
+        for (int c2 = 0; c2 < b.K; ++c2) {
+          double acc = 0.0;
+          for (int64_t q = 0; q < hr; ++q) acc += mi.H_host[(size_t)q + (size_t)hr * a] * mi.H_host[(size_t)q + (size_t)hr * c2];
+          hth[(size_t)a + (size_t)b.K * c2] = acc;
+          if (a != c2 && acc != 0.0) diag = false;
+        }
+      b.hth_diag = diag;
+      if (diag) {
+        std::vector<double> dd(b.K);
+        for (int a = 0; a < b.K; ++a) dd[a] = hth[(size_t)a + (size_t)b.K * a];
+        b.HtH.ensure((size_t)b.K * 8);
+        AO_HIP(hipMemcpyAsync(b.HtH.p, dd.data(), (size_t)b.K * 8, hipMemcpyHostToDevice, stream_));
+      } else {
+        b.HtH.ensure((size_t)b.K * b.K * 8);
+        AO_HIP(hipMemcpyAsync(b.HtH.p, hth.data(), hth.size() * 8, hipMemcpyHostToDevice, stream_));
+      }
+      AO_HIP(hipStreamSynchronize(stream_));          // hth / dd are locals
       b.have_HtH = true;
     }
-    b.Mbig.ensure((size_t)n * n * 8); b.Minv.ensure((size_t)n * n * 8);
-    par2_c_big_system(b.Lc.d(), b.HtH.d(), mi.rho.d(), con, b.K, b.R, b.Mbig.d(), stream_);
-    dense_spd_inverse(b.Mbig.d(), b.Minv.d(), n, ctl, stream_);
+    if (b.hth_diag) {
+      // row k: C(k,:) * (B_k + rhoC/2*(d_k [+ 1])*I) = A_inner(k,:); b.Lc holds B_k and is overwritten by the factors
+      par2_c_rowsys_diag(b.Lc.d(), b.HtH.d(), mi.rho.d(), con, b.K, b.R, ctl, stream_);
+    } else {
+      AO_REQUIRE(n <= kDenseMaxN, "PARAFAC2 C mode coupled with type %d through a matrix whose H'H is not diagonal: K*R = %d exceeds the dense-system limit %d", ctype, n, kDenseMaxN);
+      b.Mbig.ensure((size_t)n * n * 8); b.Minv.ensure((size_t)n * n * 8);
+      par2_c_big_system(b.Lc.d(), b.HtH.d(), mi.rho.d(), con, b.K, b.R, b.Mbig.d(), stream_);
+      dense_spd_inverse(b.Mbig.d(), b.Minv.d(), n, ctl, stream_);
+    }
   }
 }
 

@@ -203,7 +203,7 @@ def transformed_coupling_model(rng, ctype, noise=0.05):
     return Z, io
 
 
-def par2_C_coupled_model(rng, ctype, noise=0.0, K=16, I2=12, Jk=14):
+def par2_C_coupled_model(rng, ctype, noise=0.0, K=16, I2=12, Jk=14, average=False):
     """example_script14_CP_PAR2_couplC_doublesamplingrate.m:20-44 scaled down: a CP tensor whose first mode is coupled
     to the C mode (third mode) of a PARAFAC2 block.  ctype 1: H{1}*C1 = Delta = H{6}*C6 with H{6} taking every second
     of the K rows (script 14); ctype 0: C1 = C6 exactly (K rows each)."""
@@ -213,6 +213,9 @@ def par2_C_coupled_model(rng, ctype, noise=0.0, K=16, I2=12, Jk=14):
         n1 = K // 2
         sub = np.zeros((n1, K))
         sub[np.arange(n1), 2 * np.arange(n1)] = 1.0
+        if average:                                 # means of neighbouring rows: H'H is not diagonal (dense (K*R)-system)
+            sub[np.arange(n1), 2 * np.arange(n1)] = 0.5
+            sub[np.arange(n1), 2 * np.arange(n1) + 1] = 0.5
         C1 = sub @ C6
         H = [np.eye(n1), None, None, None, None, sub]
     else:

@@ -300,6 +300,20 @@ def test_cp_four_way(pkg, eng):
     compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=10)))
 
 
+def test_parafac2_C_mode_coupling_dense_system(pkg, eng):
+    """Type 1 with an H whose H'H is NOT diagonal (means of neighbouring rows): the (K*R) x (K*R) system stays dense --
+    one-workgroup Cholesky + column-parallel inverse (csrc/small.hip dense_spd_inverse).  Selection matrices (script 14)
+    take the per-row path instead, see test_parafac2_C_mode_coupling."""
+    from helpers import par2_C_coupled_model
+    for constr6 in (True, False):
+        rng = np.random.default_rng(181)
+        Z, io = par2_C_coupled_model(rng, 1, noise=0.05, average=True)
+        if not constr6:
+            Z['constrained_modes'][5] = 0
+            Z['constraints'][5] = None
+        compare_par2(*run_both(pkg, eng, Z, io, options(MaxOuterIters=10)))
+
+
 @pytest.mark.parametrize('ctype,constr6', [(0, True), (1, True), (1, False)])
 def test_parafac2_C_mode_coupling(pkg, eng, ctype, constr6):
     """example_script14 family: first mode of a CP tensor coupled to the C mode of a PARAFAC2 block.  Type 0 = per-row
