@@ -154,11 +154,11 @@ void par2_b_system(const double* GA, const double* Cfac, double w, double ridge,
 // ---------------------------------------------------------------------------
 // B-mode inner iteration
 // ---------------------------------------------------------------------------
+// One inner iteration of a slab up to the sum over the slabs is ONE kernel (par2_b_slab_k below): the three steps are
+// device functions that hand their results on through global memory + a workgroup barrier.
 // per slab: B_k update (:526-530), W = (B_k + mu_k) * DeltaB' (:532), Pold = P
-__global__ void par2_b_primal_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
-  CTL_GUARD(ctl);
-  extern __shared__ double sh[];          // L_k (R*R) then DeltaB (R*R)
-  const int k = d.k0 + blockIdx.x, R = d.R;
+__device__ __forceinline__ void par2_b_primal_dev(const P2BArgs& a, const P2Dims& d, int k, double* sh) {
+  const int R = d.R;                      // sh: L_k (R*R) then DeltaB (R*R)
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   double* Lsh = sh;
@@ -206,16 +206,13 @@ __global__ void par2_b_primal_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
 // columns, U = W*Jrot/sigma, V = Jrot.  One wave per slab: the three column products of a pair are reduced by a
 // butterfly over the 64 lanes, which leaves bit-identical sums in every lane, so each lane derives the rotation
 // itself and nothing is exchanged through memory.  W_k is staged in LDS when it fits (in_lds), else rotated in place.
-static_assert(kP2Threads == 64, "par2_polar_k reduces over exactly one wavefront");
+static_assert(kP2Threads == 64, "par2_polar_dev reduces over exactly one wavefront");
 __device__ inline double wave_sum64(double v) {
   for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
-__global__ __launch_bounds__(kP2Threads) void par2_polar_k(double* W, double* P, P2Dims d, const AdmmCtl* ctl,
-                                                            int in_lds) {
-  CTL_GUARD(ctl);
-  extern __shared__ double Jr[];          // R*R, then W_k (n*R) when in_lds
-  const int k = d.k0 + blockIdx.x, R = d.R, lane = threadIdx.x;
+__device__ __forceinline__ void par2_polar_dev(double* W, double* P, const P2Dims& d, int k, int in_lds, double* Jr) {
+  const int R = d.R, lane = threadIdx.x;  // Jr: R*R, then W_k (n*R) when in_lds
   const int64_t o = d.off[k];
   const int n = (int)(d.off[k + 1] - o);
   double* Pk = P + o * R;
@@ -272,19 +269,47 @@ __global__ __launch_bounds__(kP2Threads) void par2_polar_k(double* W, double* P,
   }
 }
 
-// part[k] = rho_k * P_k' * (B_k + mu_k)   (:541)
-__global__ void par2_deltab_part_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
-  CTL_GUARD(ctl);
-  const int k = d.k0 + blockIdx.x, R = d.R;
+// part[k] = rho_k * P_k' * (B_k + mu_k)   (:541).  With R*R < 64 outputs the rows are split over ng = 64/(R*R) groups
+// of lanes whose partial sums are added in group order (LDS), so a rank-3 block keeps 63 lanes busy instead of 9.
+__device__ __forceinline__ void par2_deltab_part_dev(const P2BArgs& a, const P2Dims& d, int k, double* sh) {
+  const int R = d.R, RR = R * R;
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
   const int64_t base = o * R;
-  for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
+  const int ng = RR < 64 ? 64 / RR : 1;
+  if (ng > 1) {
+    const int g = threadIdx.x / RR, e = threadIdx.x % RR;
+    if (g < ng) {
+      const int r = e % R, q = e / R;
+      double acc = 0.0;
+      for (int j = g; j < Jk; j += ng) acc += a.P[base + j + Jk * r] * (a.B[base + j + Jk * q] + a.mu[base + j + Jk * q]);
+      sh[g * RR + e] = acc;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < RR) {
+      double tot = 0.0;
+      for (int g2 = 0; g2 < ng; ++g2) tot += sh[g2 * RR + threadIdx.x];
+      a.part[(int64_t)k * RR + threadIdx.x] = a.rho[k] * tot;
+    }
+    return;
+  }
+  for (int e = threadIdx.x; e < RR; e += blockDim.x) {
     const int r = e % R, q = e / R;
     double acc = 0.0;
     for (int j = 0; j < Jk; ++j) acc += a.P[base + j + Jk * r] * (a.B[base + j + Jk * q] + a.mu[base + j + Jk * q]);
-    a.part[(int64_t)k * R * R + e] = a.rho[k] * acc;
+    a.part[(int64_t)k * RR + e] = a.rho[k] * acc;
   }
+}
+// primal update, polar factor and DeltaB contribution of slab k in one launch
+__global__ __launch_bounds__(kP2Threads) void par2_b_slab_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl, int in_lds) {
+  CTL_GUARD(ctl);
+  extern __shared__ double sh[];          // max(2*R*R, R*R + Jmax*R [in_lds], 64) doubles, reused by the three steps
+  const int k = d.k0 + blockIdx.x;
+  par2_b_primal_dev(a, d, k, sh);
+  __syncthreads();                        // W, B, Pold of this slab are in global memory for the whole workgroup
+  par2_polar_dev(a.W, a.P, d, k, in_lds, sh);
+  __syncthreads();
+  par2_deltab_part_dev(a, d, k, sh);
 }
 // DeltaB_old = DeltaB ; DeltaB = sum_k part[k] / sum_k rho_k   (:537-544).  With slabs sharded over ranks
 // (psum != nullptr) the kernel leaves this rank's partial sums psum[0..R*R) and psum[R*R] = sum rho_k; after the
@@ -354,13 +379,10 @@ void par2_b_iteration(const P2BArgs& a, const P2Dims& d, const AdmmCtl* ctl, hip
                       const P2AllReduce& allreduce) {
   const size_t rr = (size_t)d.R * d.R * sizeof(double);
   const unsigned nk = (unsigned)(d.k1 - d.k0);
-  par2_b_primal_k<<<nk, kP2Threads, 2 * rr, s>>>(a, d, ctl);
-  AO_KERNEL_CHECK();
   const size_t wl = (size_t)d.Jmax * d.R * sizeof(double);
   const int in_lds = rr + wl <= 48 * 1024;
-  par2_polar_k<<<nk, kP2Threads, rr + (in_lds ? wl : 0), s>>>(a.W, a.P, d, ctl, in_lds);
-  AO_KERNEL_CHECK();
-  par2_deltab_part_k<<<nk, kP2Threads, 0, s>>>(a, d, ctl);
+  const size_t lds = std::max<size_t>(std::max<size_t>(2 * rr, rr + (in_lds ? wl : 0)), 64 * sizeof(double));
+  par2_b_slab_k<<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds);
   AO_KERNEL_CHECK();
   const int ew = ksum_tile_width((int64_t)d.R * d.R);
   par2_deltab_combine_k<<<(unsigned)cdiv((int64_t)d.R * d.R, ew), kKsumThreads, 0, s>>>(a, d, ctl, ew, psum);
