@@ -581,10 +581,11 @@ __global__ void par2_c_system_k(const double* A, const double* T1, const double*
     for (int e = threadIdx.x; e < R * R; e += blockDim.x) L[(int64_t)k * R * R + e] = sh[e];
   else if (threadIdx.x == 0 && ctl) ctl->notpd = 1;
 }
-__global__ void par2_max_k(const double* x, int n, double* out, double* mean, double* sum) {
+__global__ __launch_bounds__(64) void par2_max_k(const double* x, int n, double* out, double* mean, double* sum) {
+  double m = -INFINITY, t = 0.0;                                       // lane-strided, then a 64-lane butterfly
+  for (int i = threadIdx.x; i < n; i += 64) { m = fmax(m, x[i]); t += x[i]; }
+  for (int o = 32; o > 0; o >>= 1) { m = fmax(m, __shfl_xor(m, o, 64)); t += __shfl_xor(t, o, 64); }
   if (threadIdx.x == 0) {
-    double m = x[0], t = x[0];
-    for (int i = 1; i < n; ++i) { m = fmax(m, x[i]); t += x[i]; }
     out[0] = m;                                                        // max(rho)  (:1424)
     if (sum) sum[0] = t;                                               // sum(rho)  (:736)
     if (mean) mean[0] = t / n;                                         // mean(rho) (:284, :712)
@@ -679,9 +680,10 @@ void par2_c_rowsolve(const double* a, const double* rho, const double* L, const 
 // ---------------------------------------------------------------------------
 // objective pieces
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kP2Threads) void par2_residual_k(const double* X, const double* A, const double* B,
-                                                               const double* Cfac, P2Dims d, double* res) {
-  __shared__ double red[kP2Threads];
+constexpr int kP2ResThreads = 256;        // I*J_k entries per slab: four waves
+__global__ __launch_bounds__(kP2ResThreads) void par2_residual_k(const double* X, const double* A, const double* B,
+                                                                  const double* Cfac, P2Dims d, double* res) {
+  __shared__ double red[kP2ResThreads];
   const int k = d.k0 + blockIdx.x, R = d.R, I = d.I;
   const int64_t o = d.off[k];
   const int Jk = (int)(d.off[k + 1] - o);
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(kP2Threads) void par2_residual_k(const double* X, c
 }
 void par2_residual(const double* X, const double* A, const double* B, const double* Cfac, const P2Dims& d,
                    double* res, hipStream_t s) {
-  par2_residual_k<<<d.k1 - d.k0, kP2Threads, 0, s>>>(X, A, B, Cfac, d, res);
+  par2_residual_k<<<d.k1 - d.k0, kP2ResThreads, 0, s>>>(X, A, B, Cfac, d, res);
   AO_KERNEL_CHECK();
 }
 
