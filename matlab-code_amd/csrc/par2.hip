@@ -157,6 +157,9 @@ void par2_b_system(const double* GA, const double* Cfac, double w, double ridge,
 // One inner iteration of a slab up to the sum over the slabs is ONE kernel (par2_b_slab_k below): the three steps are
 // device functions that hand their results on through global memory + a workgroup barrier.
 // per slab: B_k update (:526-530), W = (B_k + mu_k) * DeltaB' (:532), Pold = P
+// RMAX >= R is a compile-time bound: with it the per-row vectors x, bm live in registers (fully unrolled, statically
+// indexed) instead of scratch memory, which the runtime-R version needed 1 KB per lane of.
+template <int RMAX>
 __device__ __forceinline__ void par2_b_primal_dev(const P2BArgs& a, const P2Dims& d, int k, double* sh) {
   const int R = d.R;                      // sh: L_k (R*R) then DeltaB (R*R)
   const int64_t o = d.off[k];
@@ -171,33 +174,60 @@ __device__ __forceinline__ void par2_b_primal_dev(const P2BArgs& a, const P2Dims
   const double rh = a.rho[k] / 2;
   const int64_t base = o * R;
   for (int j = threadIdx.x; j < Jk; j += blockDim.x) {
-    double x[kMaxRank], bm[kMaxRank];
-    for (int r = 0; r < R; ++r) {
-      double pd = 0.0;
-      for (int q = 0; q < R; ++q) pd += a.P[base + j + Jk * q] * Dsh[q + R * r];       // (P_k*DeltaB)(j,r)
-      double v = a.Ak[base + j + Jk * r] + rh * (pd - a.mu[base + j + Jk * r]);
-      if (a.use_constr) v += rh * (a.Z[base + j + Jk * r] - a.muZ[base + j + Jk * r]);    // :527-529
-      x[r] = v;
+    double x[RMAX], bm[RMAX], pv[RMAX];
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) pv[q] = q < R ? a.P[base + j + Jk * q] : 0.0;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      x[r] = 0.0;
+      if (r < R) {
+        double pd = 0.0;
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q)
+          if (q < R) pd += pv[q] * Dsh[q + R * r];                                       // (P_k*DeltaB)(j,r)
+        double v = a.Ak[base + j + Jk * r] + rh * (pd - a.mu[base + j + Jk * r]);
+        if (a.use_constr) v += rh * (a.Z[base + j + Jk * r] - a.muZ[base + j + Jk * r]);    // :527-529
+        x[r] = v;
+      }
     }
-    for (int r = 0; r < R; ++r) {                       // forward: x*L' = rhs
-      double v = x[r];
-      for (int q = 0; q < r; ++q) v -= Lsh[r + R * q] * x[q];
-      x[r] = v / Lsh[r + R * r];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {                    // forward: x*L' = rhs
+      if (r < R) {
+        double v = x[r];
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q)
+          if (q < r) v -= Lsh[r + R * q] * x[q];
+        x[r] = v / Lsh[r + R * r];
+      }
     }
-    for (int r = R - 1; r >= 0; --r) {                  // backward: x*L = y
-      double v = x[r];
-      for (int q = r + 1; q < R; ++q) v -= Lsh[q + R * r] * x[q];
-      x[r] = v / Lsh[r + R * r];
+#pragma unroll
+    for (int r = RMAX - 1; r >= 0; --r) {               // backward: x*L = y
+      if (r < R) {
+        double v = x[r];
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q)
+          if (q > r && q < R) v -= Lsh[q + R * r] * x[q];
+        x[r] = v / Lsh[r + R * r];
+      }
     }
-    for (int r = 0; r < R; ++r) {
-      a.B[base + j + Jk * r] = x[r];
-      bm[r] = x[r] + a.mu[base + j + Jk * r];
-      a.Pold[base + j + Jk * r] = a.P[base + j + Jk * r];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      bm[r] = 0.0;
+      if (r < R) {
+        a.B[base + j + Jk * r] = x[r];
+        bm[r] = x[r] + a.mu[base + j + Jk * r];
+        a.Pold[base + j + Jk * r] = pv[r];
+      }
     }
-    for (int r = 0; r < R; ++r) {                       // W(j,r) = sum_q (B+mu)(j,q) * DeltaB(r,q)
-      double v = 0.0;
-      for (int q = 0; q < R; ++q) v += bm[q] * Dsh[r + R * q];
-      a.W[base + j + Jk * r] = v;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {                    // W(j,r) = sum_q (B+mu)(j,q) * DeltaB(r,q)
+      if (r < R) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q)
+          if (q < R) v += bm[q] * Dsh[r + R * q];
+        a.W[base + j + Jk * r] = v;
+      }
     }
   }
 }
@@ -301,11 +331,12 @@ __device__ __forceinline__ void par2_deltab_part_dev(const P2BArgs& a, const P2D
   }
 }
 // primal update, polar factor and DeltaB contribution of slab k in one launch
+template <int RMAX>
 __global__ __launch_bounds__(kP2Threads) void par2_b_slab_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl, int in_lds) {
   CTL_GUARD(ctl);
   extern __shared__ double sh[];          // max(2*R*R, R*R + Jmax*R [in_lds], 64) doubles, reused by the three steps
   const int k = d.k0 + blockIdx.x;
-  par2_b_primal_dev(a, d, k, sh);
+  par2_b_primal_dev<RMAX>(a, d, k, sh);
   __syncthreads();                        // W, B, Pold of this slab are in global memory for the whole workgroup
   par2_polar_dev(a.W, a.P, d, k, in_lds, sh);
   __syncthreads();
@@ -382,7 +413,10 @@ void par2_b_iteration(const P2BArgs& a, const P2Dims& d, const AdmmCtl* ctl, hip
   const size_t wl = (size_t)d.Jmax * d.R * sizeof(double);
   const int in_lds = rr + wl <= 48 * 1024;
   const size_t lds = std::max<size_t>(std::max<size_t>(2 * rr, rr + (in_lds ? wl : 0)), 64 * sizeof(double));
-  par2_b_slab_k<<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds);
+  if (d.R <= 4) par2_b_slab_k<4><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds);
+  else if (d.R <= 8) par2_b_slab_k<8><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds);
+  else if (d.R <= 16) par2_b_slab_k<16><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds);
+  else par2_b_slab_k<kMaxRank><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds);
   AO_KERNEL_CHECK();
   const int ew = ksum_tile_width((int64_t)d.R * d.R);
   par2_deltab_combine_k<<<(unsigned)cdiv((int64_t)d.R * d.R, ew), kKsumThreads, 0, s>>>(a, d, ctl, ew, psum);
@@ -646,34 +680,55 @@ void par2_c_big_system(const double* Bk, const double* HtH, const double* rhoC, 
   AO_KERNEL_CHECK();
 }
 
+template <int RMAX>
 __global__ void par2_c_rowsolve_k(const double* a, const double* rho, const double* L, const double* Z,
                                   const double* mu, int use_admm, P2Dims d, double* Cfac, const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
-  const int k = d.k0 + blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= d.K) return;
   const int R = d.R, K = d.K;
   const double* Lk = L + (int64_t)k * R * R;
-  double x[kMaxRank];
-  for (int r = 0; r < R; ++r) {
-    double v = a[k + K * r];
-    if (use_admm) v += rho[k] / 2 * (Z[k + K * r] - (mu ? mu[k + K * r] : 0.0));   // :604 ; coupled: Z holds the whole bracket (:640-643)
-    x[r] = v;
+  double x[RMAX];                                      // registers for RMAX <= 16 (statically indexed)
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    x[r] = 0.0;
+    if (r < R) {
+      double v = a[k + K * r];
+      if (use_admm) v += rho[k] / 2 * (Z[k + K * r] - (mu ? mu[k + K * r] : 0.0));   // :604 ; coupled: Z holds the whole bracket (:640-643)
+      x[r] = v;
+    }
   }
-  for (int r = 0; r < R; ++r) {
-    double v = x[r];
-    for (int q = 0; q < r; ++q) v -= Lk[r + R * q] * x[q];
-    x[r] = v / Lk[r + R * r];
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    if (r < R) {
+      double v = x[r];
+#pragma unroll
+      for (int q = 0; q < RMAX; ++q)
+        if (q < r) v -= Lk[r + R * q] * x[q];
+      x[r] = v / Lk[r + R * r];
+    }
   }
-  for (int r = R - 1; r >= 0; --r) {
-    double v = x[r];
-    for (int q = r + 1; q < R; ++q) v -= Lk[q + R * r] * x[q];
-    x[r] = v / Lk[r + R * r];
+#pragma unroll
+  for (int r = RMAX - 1; r >= 0; --r) {
+    if (r < R) {
+      double v = x[r];
+#pragma unroll
+      for (int q = 0; q < RMAX; ++q)
+        if (q > r && q < R) v -= Lk[q + R * r] * x[q];
+      x[r] = v / Lk[r + R * r];
+    }
   }
-  for (int r = 0; r < R; ++r) Cfac[k + K * r] = x[r];                            // :236 / :605
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r)
+    if (r < R) Cfac[k + K * r] = x[r];                                             // :236 / :605
 }
 void par2_c_rowsolve(const double* a, const double* rho, const double* L, const double* Z, const double* mu,
                      int use_admm, const P2Dims& d, double* Cfac, const AdmmCtl* ctl, hipStream_t s) {
-  par2_c_rowsolve_k<<<(d.K + 63) / 64, 64, 0, s>>>(a, rho, L, Z, mu, use_admm, d, Cfac, ctl);
+  const unsigned nb = (unsigned)((d.K + 63) / 64);
+  if (d.R <= 4) par2_c_rowsolve_k<4><<<nb, 64, 0, s>>>(a, rho, L, Z, mu, use_admm, d, Cfac, ctl);
+  else if (d.R <= 8) par2_c_rowsolve_k<8><<<nb, 64, 0, s>>>(a, rho, L, Z, mu, use_admm, d, Cfac, ctl);
+  else if (d.R <= 16) par2_c_rowsolve_k<16><<<nb, 64, 0, s>>>(a, rho, L, Z, mu, use_admm, d, Cfac, ctl);
+  else par2_c_rowsolve_k<kMaxRank><<<nb, 64, 0, s>>>(a, rho, L, Z, mu, use_admm, d, Cfac, ctl);
   AO_KERNEL_CHECK();
 }
 
