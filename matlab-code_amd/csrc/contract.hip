@@ -712,6 +712,28 @@ __device__ __forceinline__ void fma_vec(double (&acc)[VEC], const TT* __restrict
   }
 }
 
+// The same product with the loads split from the arithmetic: a loop body issues ALL its loads (tensor-side and
+// factor-side) before the first FMA.  Written as fma_vec calls back to back, the compiler re-used one register set
+// and put s_waitcnt vmcnt(0) between the groups, i.e. one 16-byte tensor load in flight per thread (4 TB/s).
+template <typename TT, int VEC>
+struct RVec {
+  typename TVec<TT, VEC>::type t;
+  double f[VEC];
+  __device__ __forceinline__ void load(const TT* __restrict__ tp, const double* __restrict__ fp) {
+    t = *reinterpret_cast<const typename TVec<TT, VEC>::type*>(tp);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) f[v] = fp[v];
+  }
+  __device__ __forceinline__ void fma(double (&acc)[VEC]) const {
+    if constexpr (VEC == 1) {
+      acc[0] += (double)t * f[0];
+    } else {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += (double)t[v] * f[v];
+    }
+  }
+};
+
 // one block per b; the A x R slab of T and the row-major factor are walked with the same flat index.
 // blockDim * VEC is a multiple of R, so a thread's r's are fixed while its a advances.
 template <typename TT, int VEC>
@@ -729,10 +751,13 @@ __global__ void reduce_inner_k(const TT* __restrict__ T, int nchunk, int64_t tro
     const TT* Tb = T + ((int64_t)ch * trows + Apad * b) * R;
     int64_t e = (int64_t)t * VEC;
     for (; e + 3 * step < n; e += 4 * step) {
-      fma_vec<TT, VEC>(s0, Tb + e, FaT + e);
-      fma_vec<TT, VEC>(s1, Tb + e + step, FaT + e + step);
-      fma_vec<TT, VEC>(s2, Tb + e + 2 * step, FaT + e + 2 * step);
-      fma_vec<TT, VEC>(s3, Tb + e + 3 * step, FaT + e + 3 * step);
+      RVec<TT, VEC> q0, q1, q2, q3;
+      q0.load(Tb + e, FaT + e);
+      q1.load(Tb + e + step, FaT + e + step);
+      q2.load(Tb + e + 2 * step, FaT + e + 2 * step);
+      q3.load(Tb + e + 3 * step, FaT + e + 3 * step);
+      __builtin_amdgcn_sched_barrier(0);               // keep the eight loads ahead of the arithmetic
+      q0.fma(s0); q1.fma(s1); q2.fma(s2); q3.fma(s3);
     }
     for (; e < n; e += step) fma_vec<TT, VEC>(s0, Tb + e, FaT + e);
   }
@@ -748,6 +773,62 @@ __global__ void reduce_inner_k(const TT* __restrict__ T, int nchunk, int64_t tro
   }
 }
 
+// Two slabs (b, b+1) per block: the factor row is loaded once and used for both, which halves the L2 -> CU traffic
+// of the factor side (fp64 factor entries are twice the bytes of the fp32 T entries they multiply).
+template <typename TT, int VEC>
+__global__ void reduce_inner2_k(const TT* __restrict__ T, int nchunk, int64_t trows, int64_t A, int64_t Apad, int64_t B,
+                                int R, const double* __restrict__ FaT, double scale, double* __restrict__ out,
+                                int64_t ldOut, int rowmajor) {
+  extern __shared__ double sh[];                      // 2 * blockDim * VEC
+  const int64_t b0 = 2 * (int64_t)blockIdx.x;
+  const bool two = b0 + 1 < B;
+  const int64_t b1 = two ? b0 + 1 : b0;
+  const int t = threadIdx.x;
+  const int64_t n = A * R, step = (int64_t)blockDim.x * VEC;
+  double a0[VEC], a1[VEC], c0[VEC], c1[VEC];           // slab b0: a0 + a1, slab b1: c0 + c1
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { a0[v] = 0; a1[v] = 0; c0[v] = 0; c1[v] = 0; }
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const TT* Ta = T + ((int64_t)ch * trows + Apad * b0) * R;
+    const TT* Tc = T + ((int64_t)ch * trows + Apad * b1) * R;
+    int64_t e = (int64_t)t * VEC;
+    for (; e + step < n; e += 2 * step) {
+      RVec<TT, VEC> q0, q1, p0, p1;
+      q0.load(Ta + e, FaT + e);
+      q1.load(Ta + e + step, FaT + e + step);
+      p0.t = *reinterpret_cast<const typename TVec<TT, VEC>::type*>(Tc + e);
+      p1.t = *reinterpret_cast<const typename TVec<TT, VEC>::type*>(Tc + e + step);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { p0.f[v] = q0.f[v]; p1.f[v] = q1.f[v]; }
+      q0.fma(a0); q1.fma(a1); p0.fma(c0); p1.fma(c1);
+    }
+    for (; e < n; e += step) {
+      RVec<TT, VEC> q0, p0;
+      q0.load(Ta + e, FaT + e);
+      p0.t = *reinterpret_cast<const typename TVec<TT, VEC>::type*>(Tc + e);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) p0.f[v] = q0.f[v];
+      q0.fma(a0); p0.fma(c0);
+    }
+  }
+  const int nt = blockDim.x * VEC;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { sh[t * VEC + v] = a0[v] + a1[v]; sh[nt + t * VEC + v] = c0[v] + c1[v]; }
+  __syncthreads();
+  if (t < 2 * R) {                                    // flat slot q holds r = q % R
+    const int which = t / R, r = t % R;
+    if (which == 0 || two) {
+      const int nA = nt / R;
+      double tot = 0.0;
+      for (int i = 0; i < nA; ++i) tot += sh[which * nt + i * R + r];
+      const int64_t b = which ? b1 : b0;
+      if (rowmajor) out[b * R + r] = scale * tot;
+      else out[b + ldOut * r] = scale * tot;
+    }
+  }
+}
+
 size_t reduce_factor_scratch_bytes(int64_t rows, int R) { return (size_t)rows * R * sizeof(double); }
 
 template <typename TT, int VEC>
@@ -757,6 +838,11 @@ static void launch_inner_t(const void* T, int nchunk, int64_t trows, int64_t A, 
   int threads = 256 / rq * rq;
   if (threads < rq) threads = rq;
   if (threads * VEC < R) threads = (R + VEC - 1) / VEC;
+  if (B >= 1024 && 2 * R <= threads) {                // enough slabs to fill the chip with half as many blocks
+    reduce_inner2_k<TT, VEC><<<(unsigned)((B + 1) / 2), threads, (size_t)2 * threads * VEC * sizeof(double), s>>>(
+        (const TT*)T, nchunk, trows, A, Apad, B, R, FaT, scale, out, ldOut, rowmajor);
+    return;
+  }
   reduce_inner_k<TT, VEC><<<(unsigned)B, threads, (size_t)threads * VEC * sizeof(double), s>>>(
       (const TT*)T, nchunk, trows, A, Apad, R, FaT, scale, out, ldOut, rowmajor);
 }
@@ -830,10 +916,13 @@ __global__ void reduce_outer_k(const TT* __restrict__ T, int nchunk, int64_t tro
     const double* Fr = FbT + r;
     int64_t b = b0;
     for (; b + 3 < b1; b += 4) {
-      fma_vec<TT, VEC>(s0, Tc + bs * b, Fr + b * R);
-      fma_vec<TT, VEC>(s1, Tc + bs * (b + 1), Fr + (b + 1) * R);
-      fma_vec<TT, VEC>(s2, Tc + bs * (b + 2), Fr + (b + 2) * R);
-      fma_vec<TT, VEC>(s3, Tc + bs * (b + 3), Fr + (b + 3) * R);
+      RVec<TT, VEC> q0, q1, q2, q3;
+      q0.load(Tc + bs * b, Fr + b * R);
+      q1.load(Tc + bs * (b + 1), Fr + (b + 1) * R);
+      q2.load(Tc + bs * (b + 2), Fr + (b + 2) * R);
+      q3.load(Tc + bs * (b + 3), Fr + (b + 3) * R);
+      __builtin_amdgcn_sched_barrier(0);
+      q0.fma(s0); q1.fma(s1); q2.fma(s2); q3.fma(s3);
     }
     for (; b < b1; ++b) fma_vec<TT, VEC>(s0, Tc + bs * b, Fr + b * R);
   }
