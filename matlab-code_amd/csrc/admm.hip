@@ -1,6 +1,8 @@
 // ADMM inner loop + proximal operators on gfx950.
 // Reference: functions/cmtf_fun_AOADMM.m:591-623 (ADMM_constrained_only), :1420-1429
 // (update_constraint), :1079-1096 (eval_res_ADMM_constr); functions/constraints_to_prox.m.
+#include <type_traits>
+
 #include "admm.h"
 #include "device_utils.h"
 #include "hosteig.h"
@@ -662,12 +664,28 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
   // ---- load (coalesced, all loads of a thread independent: a chunk-ordered loop would serialise 8-16 memory
   // round trips), mean, centred prefix sums.  The warm-start column is staged in `val` the same way.
   {
-    const double* wv = warm ? warm + ldw * r : nullptr;
-#pragma unroll 4
-    for (int i = t; i < n; i += kTvThreads) {
-      y[i] = vin[i];
-      if (wv) val[i] = wv[i];
-    }
+    // every load of the thread is issued before the first LDS store, on clamped (always valid) addresses and without
+    // an exec-mask branch in between: written as `for (i = t; i < n; i += 256) y[i] = vin[i]` the compiler emitted one
+    // s_waitcnt vmcnt(0) per element, i.e. 8-16 dependent memory round trips before the kernel could start
+    const double* wv = warm ? warm + ldw * r : vin;      // no warm start: a second read of the column, discarded
+    auto stage = [&](auto kper_tag) {
+      constexpr int KP = decltype(kper_tag)::value;
+      double ry[KP], rw[KP];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const int i = min(t + k * kTvThreads, n - 1);
+        ry[k] = vin[i];
+        rw[k] = wv[i];
+      }
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const int i = t + k * kTvThreads;
+        if (i < n) { y[i] = ry[k]; val[i] = rw[k]; }
+      }
+    };
+    if (n <= 4 * kTvThreads) stage(std::integral_constant<int, 4>());
+    else if (n <= 8 * kTvThreads) stage(std::integral_constant<int, 8>());
+    else stage(std::integral_constant<int, kTvParMax / kTvThreads>());
   }
   __syncthreads();
   double loc = 0.0;
@@ -815,27 +833,32 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
   double* Zc = fz.Z + fz.ld * r;
   double* muc = fz.mu + fz.ld * r;
   double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-  constexpr int kPer = kTvParMax / kTvThreads;                     // entries per thread at the largest n
-  double mo[kPer], zo[kPer];
+  auto dual = [&](auto kper_tag) {
+    constexpr int KP = decltype(kper_tag)::value;      // entries per thread, by the same three size classes as above
+    double mo[KP], zo[KP];
 #pragma unroll
-  for (int k = 0; k < kPer; ++k) {                                 // all loads first: stores below may alias them
-    const int i = t + k * kTvThreads;
-    mo[k] = i < n ? muc[i] : 0.0;
-    zo[k] = i < n ? Zc[i] : 0.0;
-  }
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    const int i = t + k * kTvThreads;
-    if (i < n) {
-      const double zn = val[i], vv = y[i];
-      const double x = vv - mo[k];                                 // fac = V - mu_old
-      const double mn = vv - zn;                                   // mu + fac - Z   (:1428)
-      Zc[i] = zn;
-      muc[i] = mn;
-      const double d = x - zn, e = zn - zo[k];
-      s1 += d * d; s2 += x * x; s3 += mn * mn; s4 += e * e;
+    for (int k = 0; k < KP; ++k) {                     // all loads first: stores below may alias them
+      const int i = min(t + k * kTvThreads, n - 1);
+      mo[k] = muc[i];
+      zo[k] = Zc[i];
     }
-  }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const int i = t + k * kTvThreads;
+      if (i < n) {
+        const double zn = val[i], vv = y[i];
+        const double x = vv - mo[k];                   // fac = V - mu_old
+        const double mn = vv - zn;                     // mu + fac - Z   (:1428)
+        Zc[i] = zn;
+        muc[i] = mn;
+        const double d = x - zn, e = zn - zo[k];
+        s1 += d * d; s2 += x * x; s3 += mn * mn; s4 += e * e;
+      }
+    }
+  };
+  if (n <= 4 * kTvThreads) dual(std::integral_constant<int, 4>());
+  else if (n <= 8 * kTvThreads) dual(std::integral_constant<int, 8>());
+  else dual(std::integral_constant<int, kTvParMax / kTvThreads>());
   double q4[4] = {s1, s2, s3, s4};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
