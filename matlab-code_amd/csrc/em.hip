@@ -64,10 +64,28 @@ __global__ __launch_bounds__(kEmThreads) void em_cp_k(EmCpArgs a, double* ws) {
     __syncthreads();
     const int nj = (int)((a.J - j0 < kEmJTile) ? (a.J - j0) : kEmJTile);
     if (!in_range) continue;
+    // the loads run PD columns ahead of the arithmetic (register ring): with one 16-byte load and its
+    // mask word per iteration and ~100 FMAs behind them, nothing else hides the memory latency at 4 waves per SIMD
+    constexpr int PD = 4;                              // columns in flight
+    XV xq[PD]; MV mq[PD];
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+      const int64_t op = i0 + a.Ipad * (j0 + (p < nj ? p : nj - 1));
+      xq[p] = *reinterpret_cast<const XV*>(X + op);
+      mq[p] = *reinterpret_cast<const MV*>(M + op);
+    }
     for (int jj = 0; jj < nj; ++jj) {
       const int64_t o = i0 + a.Ipad * (j0 + jj);
-      XV xv = *reinterpret_cast<const XV*>(X + o);
-      const MV mv = *reinterpret_cast<const MV*>(M + o);
+      XV xv = xq[0];
+      const MV mv = mq[0];
+#pragma unroll
+      for (int p = 0; p + 1 < PD; ++p) { xq[p] = xq[p + 1]; mq[p] = mq[p + 1]; }
+      {
+        const int jn = jj + PD < nj ? jj + PD : nj - 1;                  // clamped: the last loads are discarded
+        const int64_t on = i0 + a.Ipad * (j0 + jn);
+        xq[PD - 1] = *reinterpret_cast<const XV*>(X + on);
+        mq[PD - 1] = *reinterpret_cast<const MV*>(M + on);
+      }
       T m[VEC];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) m[v] = (T)0;
