@@ -1344,6 +1344,208 @@ __global__ void coupling_AA_k(double* AA, AAArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Couplings of type 0 (C = Delta) and 4 (C = Delta*H) are row-local: row i of every coupled factor, of Delta and of
+// the duals only ever meets row i.  One thread per row then does a whole step in registers, which turns the
+// 27 launches of an inner iteration (two modes, generic path below) into 11.  RMAX bounds both R and cols(Delta).
+struct RowCouple {
+  // per mode
+  const double* Aeff; const double* L; const double* rho; const double* H;   // H: q x R (type 4), unused for type 0
+  double* fac; double* muD; const double* Z; const double* mu;
+  int R, constrained;
+};
+template <int RMAX>
+__global__ __launch_bounds__(64) void couple_primal_rows_k(RowCouple m, const double* Delta, int64_t rows, int q, int type,
+                                                           const AdmmCtl* ctl) {
+  if (ctl != nullptr && ctl->active == 0) return;
+  extern __shared__ double sh[];                      // L (R*R), H (q*R)
+  const int R = m.R;
+  double* Lsh = sh;
+  double* Hsh = sh + R * R;
+  for (int e = threadIdx.x; e < R * R; e += blockDim.x) Lsh[e] = m.L[e];
+  if (type == 4)
+    for (int e = threadIdx.x; e < q * R; e += blockDim.x) Hsh[e] = m.H[e];
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const double rh = m.rho[0] / 2;
+  double d[RMAX], x[RMAX];
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c) d[c] = c < q ? Delta[i + rows * c] : 0.0;
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    x[r] = 0.0;
+    if (r < R) {
+      double td;
+      if (type == 4) {                                // (Delta*H)(i,r)  (:925)
+        td = 0.0;
+#pragma unroll
+        for (int c = 0; c < RMAX; ++c)
+          if (c < q) td += d[c] * Hsh[c + q * r];
+      } else {
+        td = d[r];                                    // :647
+      }
+      double v = m.Aeff[i + rows * r] + rh * (td - m.muD[i + rows * r]);
+      if (m.constrained) v += rh * (m.Z[i + rows * r] - m.mu[i + rows * r]);
+      x[r] = v;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r)                      // x * inv(L*L')  (:651, :929)
+    if (r < R) {
+      double v = x[r];
+#pragma unroll
+      for (int p = 0; p < RMAX; ++p)
+        if (p < r) v -= Lsh[r + R * p] * x[p];
+      x[r] = v / Lsh[r + R * r];
+    }
+#pragma unroll
+  for (int r = RMAX - 1; r >= 0; --r)
+    if (r < R) {
+      double v = x[r];
+#pragma unroll
+      for (int p = 0; p < RMAX; ++p)
+        if (p > r && p < R) v -= Lsh[p + R * r] * x[p];
+      x[r] = v / Lsh[r + R * r];
+    }
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r)
+    if (r < R) m.fac[i + rows * r] = x[r];
+}
+
+struct RowDelta {
+  const double* fac[8]; const double* muD[8]; const double* rho[8]; const double* H[8];
+  int R[8];
+  int n;
+};
+// Delta_old = Delta ; Delta = weighted mean (type 0, :661-675) or BB / AA (type 4, :939-963) ; dD = Delta - Delta_old
+template <int RMAX>
+__global__ __launch_bounds__(64) void couple_delta_rows_k(RowDelta a, double* Delta, double* DeltaOld, double* dD,
+                                                          const double* coefs, const double* LAA, int64_t rows, int q,
+                                                          int type, const AdmmCtl* ctl) {
+  if (ctl != nullptr && ctl->active == 0) return;
+  extern __shared__ double sh[];                      // LAA (q*q), then H_j (q*R_j) back to back
+  double* Lsh = sh;
+  if (type == 4) {
+    for (int e = threadIdx.x; e < q * q; e += blockDim.x) Lsh[e] = LAA[e];
+    int off = q * q;
+    for (int j = 0; j < a.n; ++j) {
+      for (int e = threadIdx.x; e < q * a.R[j]; e += blockDim.x) sh[off + e] = a.H[j][e];
+      off += q * a.R[j];
+    }
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  double bb[RMAX];
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c) bb[c] = 0.0;
+  int off = q * q;
+  for (int j = 0; j < a.n; ++j) {
+    if (type == 4) {
+      const double rj = a.rho[j][0];
+      double t[RMAX];
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) t[r] = r < a.R[j] ? a.fac[j][i + rows * r] + a.muD[j][i + rows * r] : 0.0;
+      const double* Hj = sh + off;
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c)
+        if (c < q) {
+          double acc = 0.0;
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r)
+            if (r < a.R[j]) acc += t[r] * Hj[c + q * r];
+          bb[c] = (j == 0 ? 0.0 : bb[c]) + rj * acc;                               // :955, same order as the gemm path
+        }
+      off += q * a.R[j];
+    } else {
+      const double cj = coefs[j];                     // rho_j / sum rho
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c)
+        if (c < q) {
+          const double v = cj * a.fac[j][i + rows * c] + cj * a.muD[j][i + rows * c];
+          bb[c] = j == 0 ? v : bb[c] + v;
+        }
+    }
+  }
+  if (type == 4) {                                    // Delta(i,:) = bb * inv(LAA*LAA')
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c)
+      if (c < q) {
+        double v = bb[c];
+#pragma unroll
+        for (int p = 0; p < RMAX; ++p)
+          if (p < c) v -= Lsh[c + q * p] * bb[p];
+        bb[c] = v / Lsh[c + q * c];
+      }
+#pragma unroll
+    for (int c = RMAX - 1; c >= 0; --c)
+      if (c < q) {
+        double v = bb[c];
+#pragma unroll
+        for (int p = 0; p < RMAX; ++p)
+          if (p > c && p < q) v -= Lsh[p + q * c] * bb[p];
+        bb[c] = v / Lsh[c + q * c];
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c)
+    if (c < q) {
+      const double old = Delta[i + rows * c];
+      DeltaOld[i + rows * c] = old;
+      Delta[i + rows * c] = bb[c];
+      dD[i + rows * c] = bb[c] - old;
+    }
+}
+
+// mu_Delta += C - Sd(Delta) and the four sums of the coupling residuals (:1099-1115, :1175-1191) for one mode:
+// out[0] = ||C - Sd(Delta)||^2, out[1] = ||mu_Delta||^2, out[2] = ||Sd(dD)||^2, out[3] = ||C||^2
+template <int RMAX>
+__global__ __launch_bounds__(256) void couple_dual_rows_k(RowCouple m, const double* Delta, const double* dD, int64_t rows,
+                                                          int q, int type, double* out, double* ws, const AdmmCtl* ctl) {
+  if (ctl != nullptr && ctl->active == 0) return;
+  extern __shared__ double sh[];                      // H (q*R)
+  __shared__ double sh4[4];
+  const int R = m.R;
+  if (type == 4)
+    for (int e = threadIdx.x; e < q * R; e += blockDim.x) sh[e] = m.H[e];
+  __syncthreads();
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+    double d[RMAX], dd[RMAX];
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) { d[c] = c < q ? Delta[i + rows * c] : 0.0; dd[c] = c < q ? dD[i + rows * c] : 0.0; }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (r < R) {
+        double td, tdd;
+        if (type == 4) {
+          td = 0.0; tdd = 0.0;
+#pragma unroll
+          for (int c = 0; c < RMAX; ++c)
+            if (c < q) { td += d[c] * sh[c + q * r]; tdd += dd[c] * sh[c + q * r]; }
+        } else { td = d[r]; tdd = dd[r]; }
+        const double f = m.fac[i + rows * r];
+        const double g = f - td;
+        const double mm = m.muD[i + rows * r] + g;                                  // :679, :967
+        m.muD[i + rows * r] = mm;
+        s0 += g * g; s1 += mm * mm; s2 += tdd * tdd; s3 += f * f;
+      }
+  }
+  s0 = block256_sum(s0, sh4); s1 = block256_sum(s1, sh4); s2 = block256_sum(s2, sh4); s3 = block256_sum(s3, sh4);
+  if (threadIdx.x == 0) {
+    double* o = gridDim.x == 1 ? out : ws + 4 * (int64_t)blockIdx.x;
+    o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+  }
+}
+__global__ void couple_dual_fin_k(double* out, const double* ws, int nb, const AdmmCtl* ctl) {
+  if (ctl != nullptr && ctl->active == 0) return;
+  if (threadIdx.x >= 4) return;
+  double t = 0.0;
+  for (int b = 0; b < nb; ++b) t += ws[4 * b + threadIdx.x];
+  out[threadIdx.x] = t;
+}
+
 void Engine::coupled_admm(int c, const aoadmm_options& opt) {
   CouplingInfo& ci = couplings_[c];
   AdmmCtl* ctl = ctl_of_coupling(c);
@@ -1403,6 +1605,79 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
       AO_KERNEL_CHECK();
     } else
     chol_only(ci.LAA.d(), ci.AA.d(), (int)ci.cols, ctl, stream_);
+  }
+  // ---- row-local fast path (types 0 and 4, ranks and cols(Delta) up to 16, no PARAFAC2 C mode)
+  {
+    int rmax = (int)ci.cols;
+    for (int j = 0; j < n; ++j) rmax = std::max(rmax, modes_[ci.modes[j]].R);
+    static const bool off = getenv("AOADMM_GENERIC_COUPLING") != nullptr;      // development switch
+    if ((ty == 0 || ty == 4) && !any_pc && rmax <= 16 && !off) {
+      const int q = (int)ci.cols;
+      const int64_t rows = ci.rows;
+      const unsigned rb = (unsigned)cdiv(rows, 64);
+      int64_t nr = cdiv(rows, 2048);
+      if (nr > 64) nr = 64;
+      RowCouple rc[8];
+      RowDelta rd;
+      rd.n = n;
+      size_t lds_delta = (size_t)q * q;
+      for (int j = 0; j < n; ++j) {
+        ModeInfo& mi = modes_[ci.modes[j]];
+        rc[j].Aeff = mi.Aeff; rc[j].L = mi.L.d(); rc[j].rho = mi.rho.d(); rc[j].H = ty == 4 ? mi.H.d() : nullptr;
+        rc[j].fac = mi.fac.d(); rc[j].muD = mi.muD.d(); rc[j].Z = mi.Z.d(); rc[j].mu = mi.mu.d();
+        rc[j].R = mi.R; rc[j].constrained = mi.constrained ? 1 : 0;
+        rd.fac[j] = mi.fac.d(); rd.muD[j] = mi.muD.d(); rd.rho[j] = mi.rho.d(); rd.H[j] = rc[j].H; rd.R[j] = mi.R;
+        lds_delta += (size_t)q * mi.R;
+      }
+      auto by_rmax = [&](auto&& launch) {
+        if (rmax <= 4) launch(std::integral_constant<int, 4>());
+        else if (rmax <= 8) launch(std::integral_constant<int, 8>());
+        else launch(std::integral_constant<int, 16>());
+      };
+      for (int it = 0; it < opt.MaxInnerIters; ++it) {
+        for (int j = 0; j < n; ++j) {                 // primal: Sd(Delta), right-hand side and row solve in one kernel
+          const size_t lds = ((size_t)rc[j].R * rc[j].R + (size_t)q * rc[j].R) * sizeof(double);
+          by_rmax([&](auto tag) {
+            couple_primal_rows_k<decltype(tag)::value><<<rb, 64, lds, stream_>>>(rc[j], ci.Delta.d(), rows, q, ty, ctl);
+          });
+          AO_KERNEL_CHECK();
+        }
+        by_rmax([&](auto tag) {                       // Delta_old, Delta, dD
+          couple_delta_rows_k<decltype(tag)::value><<<rb, 64, lds_delta * sizeof(double), stream_>>>(
+              rd, ci.Delta.d(), ci.DeltaOld.d(), ci.dD.d(), ci.coef.d(), ci.LAA.d(), rows, q, ty, ctl);
+        });
+        AO_KERNEL_CHECK();
+        FinalizeArgs fa;
+        fa.nmodes = n;
+        fa.max_inner = opt.MaxInnerIters;
+        fa.tol_pr_coupl = opt.innerRelPrTol_coupl; fa.tol_pr_constr = opt.innerRelPrTol_constr;
+        fa.tol_du_coupl = opt.innerRelDualTol_coupl; fa.tol_du_constr = opt.innerRelDualTol_constr;
+        for (int j = 0; j < n; ++j) {                 // duals, constraints, residual sums
+          const int m = ci.modes[j];
+          ModeInfo& mi = modes_[m];
+          double* sl = resid + (int64_t)m * kResidPerMode;
+          by_rmax([&](auto tag) {
+            couple_dual_rows_k<decltype(tag)::value><<<(unsigned)nr, 256, (size_t)q * mi.R * sizeof(double), stream_>>>(
+                rc[j], ci.Delta.d(), ci.dD.d(), rows, q, ty, sl + 4, redws_.d(), ctl);
+          });
+          AO_KERNEL_CHECK();
+          if (nr > 1) {
+            couple_dual_fin_k<<<1, 64, 0, stream_>>>(sl + 4, redws_.d(), (int)nr, ctl);
+            AO_KERNEL_CHECK();
+          }
+          if (mi.constrained)
+            constraint_update(mi.prox, mi.fac.d(), mi.Z.d(), mi.mu.d(), mi.Zold.d(), mi.V.d(), mi.rows, mi.R, mi.rho.d(), 1.0,
+                              mi.proxws.d(), sl, redws_.d(), ctl, stream_);
+          else
+            sumsq_diff(sl + 1, mi.fac.d(), nullptr, mi.rows * mi.R, redws_.d(), ctl, stream_);
+          fa.slots[j] = sl;
+          fa.constrained[j] = mi.constrained ? 1 : 0;
+          fa.coupled[j] = 1;
+        }
+        admm_finalize_generic(fa, ctl, stream_);
+      }
+      return;
+    }
   }
   for (int it = 0; it < opt.MaxInnerIters; ++it) {
     // ---- primal updates (:635-658, :713-730, :783-800, :853-870, :913-936, :1004-1020)
