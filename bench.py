@@ -79,7 +79,7 @@ def cpu_baseline(J, K, R, rows, full_rows):
     }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -89,13 +89,71 @@ def main():
     ap.add_argument('--prec', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rows', type=int, default=64)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit('WORLD_SIZE %d != --gpus %d' % (world, args.gpus))
+
+def launch_plan(gpus, environ, n_devices, argv, port=None):
+    """How this invocation runs (pure function, tested on CPU by tests/test_bench_launch.py).
+
+    * inside a launcher (WORLD_SIZE set): this process is one rank; WORLD_SIZE must equal --gpus;
+    * --gpus 1 without a launcher: this process is the only rank;
+    * --gpus N > 1 without a launcher: this process becomes a PARENT that never touches the GPU and starts
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`;
+      its exit code is the children's.
+    Fewer than N visible devices is an error in every case (never a silent 1-GPU number)."""
+    if gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    ws = environ.get('WORLD_SIZE')
+    if ws is not None:
+        world = int(ws)
+        if world != gpus:
+            raise SystemExit('bench.py: WORLD_SIZE=%d but --gpus %d' % (world, gpus))
+        if n_devices is not None and n_devices < int(environ.get('LOCAL_RANK', '0')) + 1:
+            raise SystemExit('bench.py: rank with LOCAL_RANK=%s but only %d GPU(s) visible'
+                             % (environ.get('LOCAL_RANK', '0'), n_devices))
+        return {'mode': 'rank', 'world': world, 'rank': int(environ.get('RANK', '0')),
+                'local_rank': int(environ.get('LOCAL_RANK', '0'))}
+    if n_devices is not None and n_devices < gpus:
+        raise SystemExit('bench.py: --gpus %d but only %d GPU(s) visible: refusing to report a smaller job under that name'
+                         % (gpus, n_devices))
+    if gpus == 1:
+        return {'mode': 'rank', 'world': 1, 'rank': 0, 'local_rank': 0}
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return {'mode': 'spawn', 'world': gpus, 'cmd': cmd}
+
+
+def visible_devices():
+    """Device count from a CHILD process (the parent of a self-launched job must not initialise the GPU)."""
+    import subprocess
+    code = ('import ctypes, sys; sys.path.insert(0, %r); import importlib; '
+            'lib = importlib.import_module("matlab-code_amd").load_library(); n = ctypes.c_int(0); '
+            'lib.aoadmm_device_count(ctypes.byref(n)); print(n.value)' % ROOT)
+    try:
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
+    in_launcher = 'WORLD_SIZE' in os.environ
+    # a lone `--gpus 1` run needs no probe either: Engine(0) fails loudly without a device
+    n_dev = visible_devices() if (not in_launcher and args.gpus > 1) else None
+    plan = launch_plan(args.gpus, os.environ, n_dev, sys.argv[1:])
+    if plan['mode'] == 'spawn':
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', '4')
+        raise SystemExit(subprocess.call(plan['cmd'], env=env))
+    rank, world, local_rank = plan['rank'], plan['world'], plan['local_rank']
     import torch
     dist = None
     if world > 1:
@@ -113,6 +171,9 @@ def main():
         # development switch: run the N > 1 data path (zero-filled own-rows buffer + ncclAllReduce of every MTTKRP
         # output) with a one-rank RCCL communicator -- the only form a one-GPU box can exercise at full size
         eng.comm_init_rank(eng.comm_unique_id(), 0, 1)
+    comm = eng.comm_info()
+    if world > 1 and comm['comm_ranks'] != world:
+        raise SystemExit('bench.py: communicator has %d ranks, expected %d' % (comm['comm_ranks'], world))
 
     I = J = K = args.size
     R = args.rank
@@ -199,6 +260,8 @@ def main():
             'mttkrp_mode1_ms': mttkrp_ms,
             'mttkrp_mfma_frac_f32_peak': flops_mttkrp / (mttkrp_ms * 1e-3) / 1e12 / (F32_MFMA_PEAK_TF * world),
             'f_tensors_last': out['f_tensors'],
+            'collectives': {'backend': 'rccl' if world > 1 else 'none', 'ranks': comm['comm_ranks'],
+                            'rccl_version': comm['rccl_version'], 'librccl': comm['librccl']},
             'datagen_s': t_gen,
             'roofline': {'bound': 'hbm', 'kernel': '%s (tensor x factor partial contraction, trailing modes)'
                                                    % ('contract16_f32' if args.prec == 'f32' else 'contract_f64'),

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AOADMM_ABI_VERSION 2
+#define AOADMM_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------ */
 enum {
@@ -45,7 +45,7 @@ enum {
                                  (cmtf_fun_AOADMM.m:142,185,273,362 throw in MATLAB) */
   AOADMM_ERR_RCCL = 4,        /* collective failure */
   AOADMM_ERR_UNSUPPORTED = 5, /* feature routed back to the MATLAB path:
-                                 non-Frobenius loss, 'custom' prox, sptensor, Z.miss */
+                                 non-Frobenius loss, 'custom' prox, sptensor */
   AOADMM_ERR_NOMEM = 6
 };
 
@@ -89,7 +89,8 @@ enum {
 /* storage / arithmetic of the big tensor passes */
 enum {
   AOADMM_PREC_F64 = 0, /* tensor stored fp64, v_mfma_f64_16x16x4_f64 (parity mode)        */
-  AOADMM_PREC_F32 = 1  /* tensor stored fp32, v_mfma_f32_32x32x2_f32, fp64 everywhere else */
+  AOADMM_PREC_F32 = 1  /* tensor stored fp32, v_mfma_f32_16x16x4_f32 (+ packed-fp32 VALU for 1-4 leftover columns),
+                          fp64 everywhere else */
 };
 
 typedef struct aoadmm_ctx aoadmm_ctx;
@@ -139,6 +140,8 @@ typedef struct aoadmm_result {
 /* Progress report of options.Display = 'iter' (cmtf_fun_AOADMM.m:44-59, :462-468): called on the caller's thread
  * from inside aoadmm_solve after the initial evaluation (iter = 0) and after every `every`-th outer iteration with
  * f = {f_tensors, f_couplings, f_constraints, f_PAR2_couplings} and f_rel_missing (NaN without Z.miss).
+ * On a multi-device context the rows are produced by rank 0's worker thread and handed to the calling thread,
+ * which delivers them while it waits inside aoadmm_solve (a MEX callback may use mexPrintf / drawnow).
  * The callback must not throw and must not call back into the library. */
 typedef void (*aoadmm_progress_fn)(void* user, int iter, const double f[4], double f_rel_missing);
 
@@ -169,6 +172,10 @@ int aoadmm_comm_init_rank(aoadmm_ctx* ctx, const char id[128], int rank, int wor
  * world > 1 on a single GPU, which RCCL refuses.  Every rank must make the same sequence of library calls. */
 int aoadmm_comm_init_local(aoadmm_ctx* ctx, int key, int rank, int world);
 int aoadmm_comm_rank(aoadmm_ctx* ctx, int* rank, int* world);
+/* What the collectives run on: ncclGetVersion() of the RCCL this process resolved, ncclCommCount() of the context's
+ * communicator (0 without one; the group size for the bring-up transport) and the path of the loaded librccl
+ * (bench.py reports all three).  Any pointer may be NULL. */
+int aoadmm_comm_info(aoadmm_ctx* ctx, int* nccl_version, int* comm_ranks, char* lib_path, int lib_path_cap);
 
 /* ---- model (the struct Z) ---------------------------------------------- */
 /* Z.size / Z.modes / Z.model / Z.weights (example_script1_CP_PAR2_nonneg.m:74-89) */
@@ -193,6 +200,7 @@ int aoadmm_model_end(aoadmm_ctx* ctx);
  * With a communicator, every rank passes the FULL array and keeps its row block,
  * or passes only its block with local_rows/row_offset != full. */
 int aoadmm_tensor_upload(aoadmm_ctx* ctx, int p, const double* data, int precision);
+/* one-process-per-GPU contexts only (a multi-device context takes the full array and shards it itself) */
 int aoadmm_tensor_upload_rows(aoadmm_ctx* ctx, int p, const double* block, int64_t row_offset,
                               int64_t local_rows, int precision);
 /* PARAFAC2 slab k (I x J_k).  k = AOADMM_ALL_SLABS: the K slabs back to back (I x sum J_k) in one transfer;

@@ -1171,12 +1171,7 @@ size_t prox_ws_bytes(int type, int64_t rows, int R) {
 static size_t tv_fast_lds(int64_t rows) { return (size_t)(4 * rows + 2) * 8 + (size_t)(rows + 2) * 4 + (size_t)rows + 64; }
 static void tv_fast_launch(const ColArgs& a, const double* warm, int64_t ldw, const TvFused& fz, const AdmmCtl* ctl,
                            hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prox_tv_fast_k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)tv_fast_lds(kTvParMax)));
-    attr = true;
-  }
+  ensure_dynamic_lds(reinterpret_cast<const void*>(prox_tv_fast_k), (int)tv_fast_lds(kTvParMax));
   prox_tv_fast_k<<<a.R, kTvThreads, tv_fast_lds(a.rows), s>>>(a, warm, ldw, fz, ctl);
   AO_KERNEL_CHECK();
 }
@@ -1211,12 +1206,7 @@ void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, 
       }
       const int use_lds = rows <= kTvLdsRows;
       const size_t sh = use_lds ? (size_t)2 * rows * sizeof(double) : 0;
-      static bool attr_set = false;
-      if (!attr_set) {
-        AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(prox_tv_k),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTvLdsRows * sizeof(double))));
-        attr_set = true;
-      }
+      ensure_dynamic_lds(reinterpret_cast<const void*>(prox_tv_k), (int)(2 * kTvLdsRows * sizeof(double)));
       prox_tv_k<<<R, 64, sh, s>>>(a, use_lds, ctl);
       break;
     }
@@ -1248,6 +1238,10 @@ template <int CPW>
 static void launch_rows(const FusedArgs& a, unsigned blocks, hipStream_t s) {
   const int RP = a.R | 1;
   const size_t sh = ((size_t)a.R * a.R + (size_t)64 * RP + 16) * sizeof(double);
+  if (sh > 65536) {                                   // R = 61..64: just above the default dynamic-LDS limit
+    ensure_dynamic_lds(reinterpret_cast<const void*>(admm_rows_k<CPW, true>), (int)sh);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(admm_rows_k<CPW, false>), (int)sh);
+  }
   if (a.R == 4 * CPW) admm_rows_k<CPW, true><<<blocks, kRowBlock, sh, s>>>(a);
   else admm_rows_k<CPW, false><<<blocks, kRowBlock, sh, s>>>(a);
 }

@@ -3,8 +3,10 @@
 #include <rccl/rccl.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -32,6 +34,22 @@ struct MultiCtx {
   bool quit = false;
   std::vector<int> code;
   std::vector<std::string> msg;
+  std::vector<char> done;
+  // options.Display = 'iter': rank 0's worker queues the rows, the CALLING thread delivers them from inside run()
+  // (a MEX callback may only touch MATLAB from the interpreter's thread)
+  struct ProgressRow { int iter; double f[4]; double frm; };
+  std::deque<ProgressRow> rows;
+  aoadmm_progress_fn user_fn = nullptr;
+  void* user_arg = nullptr;
+  static void queue_row(void* self, int iter, const double f[4], double frm) {
+    MultiCtx* mc = static_cast<MultiCtx*>(self);
+    ProgressRow r;
+    r.iter = iter; r.frm = frm;
+    for (int i = 0; i < 4; ++i) r.f[i] = f[i];
+    std::lock_guard<std::mutex> lk(mc->m);
+    mc->rows.push_back(r);
+    mc->cv_done.notify_all();
+  }
 
   void worker(int r, int device) {
     uint64_t seen = 0;
@@ -55,23 +73,58 @@ struct MultiCtx {
       catch (...) { c = AOADMM_ERR_INVALID; w = "unknown failure"; }
       {
         std::lock_guard<std::mutex> lk(m);
-        code[r] = c; msg[r] = w;
-        if (--pending == 0) cv_done.notify_all();
+        code[r] = c; msg[r] = w; done[r] = 1;
+        --pending;
+        cv_done.notify_all();             // also on failure: run() starts its grace period for the peers
       }
     }
   }
-  // run f on every engine concurrently; throws the first rank's failure
+  // run f on every engine concurrently; progress rows are delivered on this (the caller's) thread while it waits.
+  // Throws the failure of the rank that failed by itself: a rank that only reports the abort it received
+  // (AOADMM_ERR_RCCL) is passed over when another rank has the cause.
   void run(const std::function<void(Engine&, int)>& f) {
     {
       std::unique_lock<std::mutex> lk(m);
       job = f;
       pending = (int)eng.size();
+      done.assign(eng.size(), 0);
+      code.assign(eng.size(), AOADMM_OK);
       ++gen;
       cv_job.notify_all();
-      cv_done.wait(lk, [&] { return pending == 0; });
+      // A rank that failed alone leaves its peers waiting for it inside a collective.  Failures that every rank
+      // detects (bad arguments) finish everywhere within milliseconds; if some rank is still busy kAbortGrace after
+      // another one failed, its communicator is aborted so that it returns (the context is unusable afterwards).
+      const auto kAbortGrace = std::chrono::seconds(5);
+      bool failing = false, aborted = false;
+      std::chrono::steady_clock::time_point t_fail;
+      for (;;) {
+        cv_done.wait_for(lk, std::chrono::milliseconds(500), [&] { return pending == 0 || !rows.empty(); });
+        if (!aborted && pending > 0) {
+          bool any = false;
+          for (size_t r = 0; r < eng.size(); ++r) any = any || (done[r] && code[r] != AOADMM_OK);
+          if (any && !failing) { failing = true; t_fail = std::chrono::steady_clock::now(); }
+          if (failing && std::chrono::steady_clock::now() - t_fail > kAbortGrace) {
+            for (size_t r = 0; r < eng.size(); ++r)
+              if (!done[r]) eng[r]->comm_abort();
+            aborted = true;
+          }
+        }
+        while (!rows.empty()) {
+          const ProgressRow r = rows.front();
+          rows.pop_front();
+          aoadmm_progress_fn fn = user_fn;
+          void* arg = user_arg;
+          lk.unlock();
+          if (fn) fn(arg, r.iter, r.f, r.frm);
+          lk.lock();
+        }
+        if (pending == 0) break;
+      }
     }
+    int first = -1;
     for (size_t r = 0; r < eng.size(); ++r)
-      if (code[r] != AOADMM_OK) throw Error(code[r], fmt("rank %d: %s", (int)r, msg[r].c_str()));
+      if (code[r] != AOADMM_OK && (first < 0 || (code[first] == AOADMM_ERR_RCCL && code[r] != AOADMM_ERR_RCCL))) first = (int)r;
+    if (first >= 0) throw Error(code[first], fmt("rank %d: %s", first, msg[first].c_str()));
   }
   ~MultiCtx() {
     {
@@ -154,7 +207,7 @@ int aoadmm_create_multi(aoadmm_ctx** ctx, int n_devices, const int* devices) {
     *ctx = nullptr;
     std::unique_ptr<MultiCtx> mc(new MultiCtx);
     const int n = n_devices;
-    mc->eng.resize(n); mc->code.assign(n, AOADMM_OK); mc->msg.resize(n);
+    mc->eng.resize(n); mc->code.assign(n, AOADMM_OK); mc->msg.resize(n); mc->done.assign(n, 0);
     for (int r = 0; r < n; ++r) mc->eng[r].reset(new Engine(devices[r]));
     for (int r = 0; r < n; ++r) mc->th.emplace_back(&MultiCtx::worker, mc.get(), r, devices[r]);
     bool distinct = true;
@@ -203,8 +256,18 @@ int aoadmm_synchronize(aoadmm_ctx* ctx) {
 
 int aoadmm_set_progress(aoadmm_ctx* ctx, aoadmm_progress_fn fn, void* user, int every) {
   CTX_OR_FAIL(ctx);
-  return guarded([&] {                               // rank 0 reports
-    on_engines(ctx, [&](Engine& e, int r) { e.set_progress(r == 0 ? fn : nullptr, r == 0 ? user : nullptr, r == 0 ? every : 0); });
+  return guarded([&] {                               // rank 0 reports; the caller's thread delivers (MultiCtx::run)
+    if (ctx->multi) {
+      MultiCtx* mc = ctx->multi;
+      { std::lock_guard<std::mutex> lk(mc->m); mc->user_fn = fn; mc->user_arg = user; }
+      const bool on = fn != nullptr && every > 0;
+      on_engines(ctx, [&](Engine& e, int r) {
+        const bool mine = on && r == 0;
+        e.set_progress(mine ? &MultiCtx::queue_row : nullptr, mine ? static_cast<void*>(mc) : nullptr, mine ? every : 0);
+      });
+    } else {
+      ctx->eng->set_progress(fn, user, every);
+    }
   });
 }
 
@@ -238,6 +301,10 @@ int aoadmm_comm_rank(aoadmm_ctx* ctx, int* rank, int* world) {
     if (rank) *rank = ctx->eng->rank();
     if (world) *world = ctx->eng->world();
   });
+}
+int aoadmm_comm_info(aoadmm_ctx* ctx, int* nccl_version, int* comm_ranks, char* lib_path, int lib_path_cap) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] { ctx->eng->comm_info(nccl_version, comm_ranks, lib_path, lib_path_cap); });
 }
 
 int aoadmm_model_begin(aoadmm_ctx* ctx, int n_modes, int n_tensors, int n_couplings) {
@@ -307,7 +374,10 @@ int aoadmm_tensor_upload_rows(aoadmm_ctx* ctx, int p, const double* block, int64
   CTX_OR_FAIL(ctx);
   return guarded([&] {
     AO_REQUIRE(block != nullptr && local_rows > 0, "null/empty block");
-    on_engines(ctx, [&](Engine& e, int) { e.tensor_upload(p, block, precision, row_offset, local_rows); });
+    // one block cannot be every rank's block: a multi-device context shards the FULL array itself
+    AO_REQUIRE(!ctx->multi, "aoadmm_tensor_upload_rows is for one-process-per-GPU contexts; give a multi-device context "
+                            "the full array through aoadmm_tensor_upload");
+    ctx->eng->tensor_upload(p, block, precision, row_offset, local_rows);
   });
 }
 int aoadmm_par2_slab_upload(aoadmm_ctx* ctx, int p, int k, const double* Xk) {
@@ -409,7 +479,8 @@ int aoadmm_op_mttkrp(aoadmm_ctx* ctx, const double* X, int ndims, const int64_t*
     }
     DevBuf o;
     o.alloc((size_t)dims[n] * R * sizeof(double));
-    e.block_mttkrp(blk, n, refs, R, 1.0, o.d(), dims[n], false, nullptr, 0);
+    // host in / host out on ONE engine with the whole tensor: no collective, whatever communicator the engine is in
+    e.block_mttkrp(blk, n, refs, R, 1.0, o.d(), dims[n], false, nullptr, 0, false);
     d2h(out, o, dims[n] * R, e.stream());
   });
 }

@@ -81,4 +81,9 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 constexpr int kMaxRank = 64;   // R <= 64 (two 32-wide MFMA N tiles); typical R <= 32
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a (device, kernel) pair, not to the process: a context that
+// drives several devices from one process (aoadmm_create_multi) must opt in on each of them.  Thread-safe; a
+// larger request for a pair that already opted in raises the limit.  (misc.hip)
+void ensure_dynamic_lds(const void* kernel, int bytes);
+
 }  // namespace aoadmm

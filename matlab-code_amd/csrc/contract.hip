@@ -601,13 +601,12 @@ static void launch_contract_lead(const void* X, const ContractPlan& pl, const do
   const int64_t total = (int64_t)nt16 * Cg16 * 256;
   pack_frag_lead16_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, nt16, Cg16, (float*)frag_ws);
   AO_KERNEL_CHECK();
-  static bool attr16 = false;
-  if (!attr16) {
-#define AO_SET(K) AO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    AO_SET(contract_lead16_f32<1>) AO_SET(contract_lead16_f32<2>) AO_SET(contract_lead16_f32<3>) AO_SET(contract_lead16_f32<4>)
+#define AO_SET(K) ensure_dynamic_lds(reinterpret_cast<const void*>(K), (int)sh);
+  if (nt16 == 1) AO_SET(contract_lead16_f32<1>)
+  else if (nt16 == 2) AO_SET(contract_lead16_f32<2>)
+  else if (nt16 == 3) AO_SET(contract_lead16_f32<3>)
+  else if (nt16 == 4) AO_SET(contract_lead16_f32<4>)
 #undef AO_SET
-    attr16 = true;
-  }
   if (ev0) AO_HIP(hipEventRecord(ev0, s));
   if (nt16 == 1) contract_lead16_f32<1><<<grid, 256, sh, s>>>(a);
   else if (nt16 == 2) contract_lead16_f32<2><<<grid, 256, sh, s>>>(a);

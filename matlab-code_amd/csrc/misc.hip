@@ -1,7 +1,24 @@
 // Data movement / generation helpers (see misc.h).
 #include "misc.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace aoadmm {
+
+void ensure_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> granted;
+  int dev = 0;
+  AO_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  int& have = granted[std::make_pair(dev, kernel)];
+  if (have >= bytes) return;
+  AO_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  have = bytes;
+}
+
 
 // ---------------------------------------------------------------------------
 template <typename T>

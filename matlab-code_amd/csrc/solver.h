@@ -3,7 +3,9 @@
 // resident in HBM; the host synchronises once per outer iteration to read the
 // objective values and the inner-iteration counters.
 #pragma once
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "admm.h"
@@ -189,6 +191,11 @@ class Engine {
   // communicator
   void comm_init(const char id[128], int rank, int world);
   void comm_init_local(int key, int rank, int world);
+  // Unblocks this engine's collectives after a failure on ANOTHER rank of the same process (aoadmm_create_multi):
+  // callable from a foreign thread while the engine's own thread waits inside a collective; the next collective
+  // throws AOADMM_ERR_RCCL.  The communicator is gone afterwards.
+  void comm_abort();
+  void comm_info(int* nccl_version, int* comm_ranks, char* lib_path, int cap) const;
   void set_progress(aoadmm_progress_fn fn, void* user, int every) { progress_fn_ = fn; progress_user_ = user; progress_every_ = every; }
   void par2_gather_slabs(TensorInfo& t);
   bool sharded() const { return comm_ != nullptr || local_ != nullptr; }
@@ -205,8 +212,10 @@ class Engine {
   bool ensure_permuted_copy2(CpBlock& b);
   void drop_permuted_copies(CpBlock& b);
   void prefetch_next_contraction(const aoadmm_options& opt);
+  // `collective` = false: the block holds the whole tensor and the result is complete on this engine (op-level
+  // entry on an engine that happens to belong to a communicator)
   void block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
-                    int64_t ldOut, bool use_cache, const int* update_seq, int nseq);
+                    int64_t ldOut, bool use_cache, const int* update_seq, int nseq, bool collective = true);
   void block_upload(CpBlock& b, int nd, const int64_t* dims, const double* host, int prec, int64_t row0,
                     int64_t local_rows);
   void allreduce(double* buf, int64_t n);
@@ -256,6 +265,8 @@ class Engine {
   KernelStats kstats_[2];   // [0] streaming contraction, [1] leading-mode contraction
   bool profile_ = true;
   ncclComm_t comm_ = nullptr;
+  mutable std::mutex comm_mu_;          // comm_ / aborted_ against comm_abort() from another worker thread
+  std::atomic<bool> aborted_{false};
   std::shared_ptr<LocalGroup> local_;   // process-local group (threads of one process), see solver.hip
   int rank_ = 0, world_ = 1;
   aoadmm_progress_fn progress_fn_ = nullptr;   // options.Display = 'iter'

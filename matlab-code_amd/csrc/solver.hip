@@ -7,6 +7,7 @@
 #include "hosteig.h"
 
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -69,6 +70,7 @@ void Engine::comm_init(const char id[128], int rank, int world) {
   }
   rank_ = rank;
   world_ = world;
+  aborted_ = false;
 }
 
 // Process-local group: engines driven by threads of ONE process (on one device or several) meet at a
@@ -81,9 +83,11 @@ struct LocalGroup {
   std::condition_variable cv;
   int world = 0, arrived = 0, joined = 0;
   uint64_t gen = 0;
+  bool aborted = false;                       // a rank failed outside the collectives: nobody waits for it any more
   std::vector<std::vector<double>> stage;     // one host buffer per rank
   void barrier() {
     std::unique_lock<std::mutex> lk(m);
+    if (aborted) throw Error(AOADMM_ERR_RCCL, "local group: aborted after a failure on another rank");
     const uint64_t g = gen;
     if (++arrived == world) {
       arrived = 0;
@@ -91,8 +95,14 @@ struct LocalGroup {
       cv.notify_all();
       return;
     }
-    if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g; }))
+    if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return gen != g || aborted; }))
       throw Error(AOADMM_ERR_RCCL, "local group: a rank did not reach the collective within 120 s");
+    if (gen == g) throw Error(AOADMM_ERR_RCCL, "local group: aborted after a failure on another rank");
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lk(m);
+    aborted = true;
+    cv.notify_all();
   }
 };
 static std::mutex g_groups_mutex;
@@ -113,10 +123,44 @@ void Engine::comm_init_local(int key, int rank, int world) {
   local_ = g;
   rank_ = rank;
   world_ = world;
+  aborted_ = false;
+}
+
+void Engine::comm_abort() {
+  aborted_ = true;
+  if (local_) local_->abort();
+  std::lock_guard<std::mutex> lk(comm_mu_);
+  if (comm_) {
+    (void)ncclCommAbort(comm_);                 // the collective kernels of this rank see the flag and exit
+    comm_ = nullptr;
+  }
+}
+
+void Engine::comm_info(int* nccl_version, int* comm_ranks, char* lib_path, int cap) const {
+  if (nccl_version) {
+    int v = 0;
+    AO_NCCL(ncclGetVersion(&v));
+    *nccl_version = v;
+  }
+  if (comm_ranks) {
+    int n = local_ ? world_ : 0;
+    std::lock_guard<std::mutex> lk(comm_mu_);
+    if (comm_) AO_NCCL(ncclCommCount(comm_, &n));
+    *comm_ranks = n;
+  }
+  if (lib_path && cap > 0) {
+    lib_path[0] = 0;
+    Dl_info di;
+    if (dladdr(reinterpret_cast<const void*>(&ncclGetVersion), &di) && di.dli_fname) {
+      std::strncpy(lib_path, di.dli_fname, (size_t)cap - 1);
+      lib_path[cap - 1] = 0;
+    }
+  }
 }
 
 void Engine::allreduce(double* buf, int64_t n) {
   if (n <= 0) return;
+  if (aborted_) throw Error(AOADMM_ERR_RCCL, "communicator aborted after a failure on another rank");
   if (local_) {
     LocalGroup& g = *local_;
     std::vector<double>& mine = g.stage[rank_];
@@ -135,6 +179,7 @@ void Engine::allreduce(double* buf, int64_t n) {
     AO_HIP(hipStreamSynchronize(stream_));
     return;
   }
+  std::lock_guard<std::mutex> lk(comm_mu_);
   if (!comm_) return;
   AO_NCCL(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, comm_, stream_));
 }
@@ -471,7 +516,9 @@ void Engine::tensor_upload(int p, const double* data, int prec, int64_t row0, in
     int64_t per = cdiv(I, world_);
     row0 = std::min<int64_t>(I, per * rank_);
     local_rows = std::min<int64_t>(I, row0 + per) - row0;
-    AO_REQUIRE(local_rows > 0, "rank %d owns no rows of tensor %d (first mode %lld rows, %d ranks)", rank_, p, (long long)I, world_);
+    // the same verdict on every rank (a rank that throws alone leaves the others waiting in the next collective)
+    AO_REQUIRE(per * (world_ - 1) < I, "tensor %d: first mode of %lld rows cannot be split over %d ranks (the last rank would own no rows)",
+               p, (long long)I, world_);
     if (world_ == 1) {
       block_upload(t.blk, t.nmodes, dims, data, prec, 0, I);
     } else {
@@ -490,6 +537,11 @@ void Engine::tensor_upload(int p, const double* data, int prec, int64_t row0, in
 
 double Engine::tensor_normsq(int p) {
   AO_REQUIRE(p >= 0 && p < n_tensors_, "tensor %d out of range", p);
+  // test hook (tests/test_gpu_sharded.py): AOADMM_FAULT_INJECT=normsq:<rank> makes that rank fail ALONE in front of
+  // a collective, the situation MultiCtx::run's abort path exists for (a device error or OOM on one GPU)
+  if (const char* fi = getenv("AOADMM_FAULT_INJECT"))
+    if (std::strncmp(fi, "normsq:", 7) == 0 && std::atoi(fi + 7) == rank_ && world_ > 1)
+      throw Error(AOADMM_ERR_HIP, "injected fault (AOADMM_FAULT_INJECT)");
   TensorInfo& t = tensors_[p];
   AO_REQUIRE(t.blk.has_data, "tensor %d has no data", p);
   if (!t.normsq_valid) {
@@ -534,7 +586,8 @@ void Engine::tensor_synth(int p, int rank, uint64_t seed, double noise, int prec
   const int64_t per = cdiv(I, world_);
   const int64_t row0 = std::min<int64_t>(I, per * rank_);
   const int64_t loc = std::min<int64_t>(I, row0 + per) - row0;
-  AO_REQUIRE(loc > 0, "rank %d owns no rows", rank_);
+  AO_REQUIRE(per * (world_ - 1) < I, "tensor %d: first mode of %lld rows cannot be split over %d ranks (the last rank would own no rows)",
+             p, (long long)I, world_);           // the same verdict on every rank
   CpBlock& b = t.blk;
   b.nd = 3; b.full0 = I; b.row0 = row0;
   b.dims[0] = loc; b.dims[1] = J; b.dims[2] = K;
@@ -958,12 +1011,12 @@ void Engine::prefetch_next_contraction(const aoadmm_options& opt) {
 }
 
 void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
-                          int64_t ldOut, bool use_cache, const int* update_seq, int nseq) {
+                          int64_t ldOut, bool use_cache, const int* update_seq, int nseq, bool collective) {
   AO_REQUIRE(b.has_data, "tensor has no data");
   AO_REQUIRE(pos >= 0 && pos < b.nd, "mttkrp: mode %d out of range", pos);
   const int prec = b.X.prec;
   const int64_t I = b.dims[0], Ip = b.X.pad0;
-  const bool sharded = this->sharded();
+  const bool sharded = collective && this->sharded();
   double* out_local = out;
   const int64_t out_rows_full = (pos == 0) ? b.full0 : b.dims[pos];
   if (sharded && pos == 0) {
@@ -2016,11 +2069,11 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
       const bool can = sharded() && world_ > 1 && !b.has_mask && !(mB.constrained && mB.prox.type == AOADMM_C_TPARAFAC2) &&
                        modes_[t.modes[2]].coupling < 0;     // a coupled C mode needs every row system on every rank
       const bool want = opt.par2_slab_sharding > 0 || (opt.par2_slab_sharding == 0 && b.K / world_ >= 1024);
-      b.slab_sharded = can && want;
       const int per = (int)cdiv(b.K, world_);
+      // every rank must own a slab, and every rank must reach the same verdict: otherwise repeat the block
+      b.slab_sharded = can && want && (int64_t)per * (world_ - 1) < b.K;
       b.k0 = std::min(b.K, per * rank_);
       b.k1 = std::min(b.K, b.k0 + per);
-      AO_REQUIRE(!b.slab_sharded || b.k1 > b.k0, "rank %d owns no slab of PARAFAC2 block %d (%d slabs, %d ranks)", rank_, p + 1, b.K, world_);
     }
     par2_gram(modes_[t.modes[1]].fac.d(), b.dims(), b.GB.d(), stream_);      // :71-73
     t.last_pos = 2;

@@ -94,6 +94,13 @@ class Engine:
         capi.check(self.lib.aoadmm_comm_rank(self.h, C.byref(r), C.byref(w)))
         return r.value, w.value
 
+    def comm_info(self):
+        """{'rccl_version', 'comm_ranks', 'librccl'}: what the collectives of this context run on."""
+        v, n = C.c_int(0), C.c_int(0)
+        buf = C.create_string_buffer(1024)
+        capi.check(self.lib.aoadmm_comm_info(self.h, C.byref(v), C.byref(n), buf, 1024))
+        return {'rccl_version': v.value, 'comm_ranks': n.value, 'librccl': buf.value.decode('utf-8', 'replace')}
+
     def comm_init_local(self, key, rank, world):
         """Bring-up/test transport: engines driven by threads of this process form group `key` (see aoadmm_hip.h)."""
         capi.check(self.lib.aoadmm_comm_init_local(self.h, int(key), int(rank), int(world)))

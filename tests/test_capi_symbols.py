@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg.load_library()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.aoadmm_abi_version() == 2
+    assert lib.aoadmm_abi_version() == 3
 
 
 def test_struct_layouts(pkg):

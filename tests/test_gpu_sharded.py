@@ -219,3 +219,77 @@ def test_multi_device_context_reports_errors(pkg):
         assert 'rank 0' in str(ei.value)
         with pytest.raises(capi.AoadmmError):
             e.comm_init_local(1, 0, 2)                 # the context owns its communicator
+
+
+def test_multi_device_progress_runs_on_the_callers_thread(pkg):
+    """options.Display = 'iter' on a multi-device context: rank 0's worker thread produces the rows, the CALLING thread
+    delivers them (include/aoadmm_hip.h: a MEX callback may only touch MATLAB from the interpreter's thread)."""
+    capi = __import__('importlib').import_module('matlab-code_amd._capi')
+    rng = np.random.default_rng(5)
+    Z, io, _ = cp_model((21, 9, 8), 2, rng, [('non-negativity',)] * 3)
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(7))
+    seen = []
+    cb = capi.PROGRESS_FN(lambda user, it, f, frm: seen.append((threading.get_ident(), it, f[0])))
+    with pkg.Engine([0, 0]) as e:
+        capi.check(e.lib.aoadmm_set_progress(e.h, cb, None, 2))
+        _, _, _, og = pkg.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=6), init=copy.deepcopy(G), engine=e)
+        capi.check(e.lib.aoadmm_set_progress(e.h, capi.PROGRESS_FN(0), None, 0))
+    assert [s[1] for s in seen] == [0, 2, 4, 6]
+    assert all(s[0] == threading.get_ident() for s in seen), 'progress callback left the calling thread'
+    assert seen[-1][2] == og['func_val_conv'][6]
+
+
+def test_rank_uniform_ownership_checks(pkg):
+    """Decisions that depend on the rank are the same on every rank: 9 rows over 8 engines is refused by ALL of them
+    (ranks 5-7 would own nothing) instead of three ranks throwing while five wait in the next collective; 5 PARAFAC2
+    slabs over 4 engines with sharding forced fall back to the repeated block everywhere."""
+    from helpers import script4_model
+    capi = __import__('importlib').import_module('matlab-code_amd._capi')
+    rng = np.random.default_rng(3)
+    Z, io, _ = cp_model((9, 6, 5), 2, rng, [('non-negativity',)] * 3)
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(7))
+    with pkg.Engine([0] * 8) as e:
+        with pytest.raises(capi.AoadmmError) as ei:
+            pkg.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=2), init=copy.deepcopy(G), engine=e)
+        assert 'cannot be split over 8 ranks' in str(ei.value)
+    Z4, io4 = script4_model(np.random.default_rng(10), K=5)
+    G4 = OA.init_coupled_AOADMM_CMTF({**Z4, 'prox_operators': None}, io4, rng=np.random.default_rng(7))
+    opt = options(MaxOuterIters=4)
+    _, Fo, _, oo = OA.cmtf_AOADMM(Z4, alg_options=opt, init=copy.deepcopy(G4))
+    with pkg.Engine([0] * 4) as e:
+        _, Fg, _, og = pkg.cmtf_AOADMM(Z4, alg_options=dict(opt, hip=dict(par2_slab_sharding=1)), init=copy.deepcopy(G4), engine=e)
+    compare_par2(Fo, oo, Fg, og)
+
+
+def test_multi_device_lone_failure_does_not_hang(pkg, monkeypatch):
+    """One rank fails alone in front of a collective (injected): the caller gets that rank's error after the grace
+    period instead of waiting for ever on the peers that sit in the collective."""
+    import time
+    capi = __import__('importlib').import_module('matlab-code_amd._capi')
+    rng = np.random.default_rng(5)
+    Z, io, _ = cp_model((21, 9, 8), 2, rng, [('non-negativity',)] * 3)
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(7))
+    monkeypatch.setenv('AOADMM_FAULT_INJECT', 'normsq:1')
+    t0 = time.time()
+    with pkg.Engine([0, 0, 0]) as e:
+        with pytest.raises(capi.AoadmmError) as ei:
+            pkg.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=3), init=copy.deepcopy(G), engine=e)
+    assert 'rank 1' in str(ei.value) and 'injected fault' in str(ei.value)
+    assert time.time() - t0 < 60
+
+
+def test_op_level_calls_on_a_multi_device_context(pkg):
+    """Host-in/host-out op-level entries run on one engine without a collective, whatever communicator it is in;
+    aoadmm_tensor_upload_rows (one block for every rank) is refused."""
+    import ctypes as C
+    capi = __import__('importlib').import_module('matlab-code_amd._capi')
+    from oracle.tensor_ops import mttkrp as mttkrp_ref
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((11, 7, 5))
+    U = [rng.standard_normal((n, 3)) for n in X.shape]
+    with pkg.Engine([0, 0]) as e:
+        for n in range(3):
+            assert rel_fro(e.mttkrp(X, U, n), mttkrp_ref(X, U, n)) < 1e-12
+        blk = capi.as_f(X[:5].reshape(5, -1, order='F'))
+        st = e.lib.aoadmm_tensor_upload_rows(e.h, 0, capi.dptr(blk), 0, 5, capi.PREC_F64)
+        assert st == capi.ERR_INVALID
