@@ -43,6 +43,8 @@ struct ContractPlan {
   double flops() const { return 2.0 * nbatch * M * C * R; }
 };
 
+extern int g_contract_variant;   // development switch (see contract.hip); -1 = read AOADMM_CONTRACT_VARIANT
+
 ContractPlan make_plan(int64_t nbatch, int64_t batch_stride, int64_t M, int64_t ld, int64_t C, int R,
                        int prec);
 

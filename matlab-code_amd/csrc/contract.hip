@@ -37,23 +37,6 @@ static constexpr int kGroup = 8;          // reduction columns per pipeline stag
 // ---------------------------------------------------------------------------
 // operand packing: factor matrix (C x R, fp64 col-major) -> MFMA B fragments
 // ---------------------------------------------------------------------------
-// f64 layout: frag[nt][g][lane][e], value F[8g + 4e + (lane>>4)][16nt + (lane&15)]
-__global__ void pack_frag_f64(const double* __restrict__ F, int64_t ldF, int64_t C, int R, int NT,
-                              int64_t Cg, double* __restrict__ frag) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over nt*Cg*64*2
-  int64_t total = (int64_t)NT * Cg * 128;
-  if (idx >= total) return;
-  int e = idx & 1;
-  int lane = (idx >> 1) & 63;
-  int64_t g = (idx >> 7) % Cg;
-  int nt = (int)((idx >> 7) / Cg);
-  int64_t c = 8 * g + 4 * e + (lane >> 4);
-  int r = 16 * nt + (lane & 15);
-  double v = 0.0;
-  if (c < C && r < R) v = F[c + ldF * r];
-  frag[idx] = v;
-}
-
 // arguments of the register-streaming contractions (contract16_f32, contract_f64)
 struct KArgs {
   const void* X;
@@ -225,9 +208,14 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract16_f32(KArgs a) 
 #undef AO_FMA_S
 #undef AO_COMPUTE_STAGE
 #undef AO_MIX_STAGE
-  // epilogue: 16x16 C/D map col = lane&15, row j = 4*(lane>>4) + reg; tile (half, v) row j is
-  // unfolding row m0 + 64*half + 4*j + v
-  float* Tc = reinterpret_cast<float*>(a.T) + ((int64_t)chunk * a.trows + b * a.M) * a.R;
+  // epilogue.  16x16 C/D map: col = lane&15, row j = 4*(lane>>4) + reg; tile (half, v) row j is unfolding row
+  // m0 + 64*half + 4*j + v.  The wave's 128 x R tile of T is ONE contiguous range of 512*R bytes, so it is assembled
+  // in the wave's own slice of LDS and leaves as 16-byte, fully coalesced stores of whole cache lines.  (Storing the
+  // C/D registers directly -- 4-byte stores, 64-byte pieces of 80-byte rows -- cost 0.4-1.1 ms of a 5.3 ms pass at
+  // 2000^3: partial lines are read-modified-written in L2 and trickle into HBM between the reads, and how much that
+  // hurts depends on where X and T happen to lie; tools/micro/pass_placement.hip)
+  extern __shared__ __attribute__((aligned(16))) float t_lds[];
+  float* tl = t_lds + (threadIdx.x >> 6) * (kTileRows * a.R);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int r = 16 * nt + r16;
@@ -237,10 +225,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract16_f32(KArgs a) 
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int64_t m = m0 + 64 * h + 4 * (4 * q + i) + v;
-            if (m < a.M) Tc[m * a.R + r] = acc[nt][h][v][i];
-          }
+          for (int i = 0; i < 4; ++i) tl[(64 * h + 4 * (4 * q + i) + v) * a.R + r] = acc[nt][h][v][i];
     }
   }
   if (EX) {
@@ -261,15 +246,21 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract16_f32(KArgs a) 
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int64_t m = m0 + 64 * h + 4 * r16 + v;
-          if (m < a.M) {
+        for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (e < ne) Tc[m * a.R + 16 * NT + e] = accE[h][v][e >> 1][e & 1];
-          }
-        }
+          for (int e = 0; e < 4; ++e)
+            if (e < ne) tl[(64 * h + 4 * r16 + v) * a.R + 16 * NT + e] = accE[h][v][e >> 1][e & 1];
     }
+  }
+  // a wave's LDS operations complete in order: its own writes are visible to its reads without a barrier
+  {
+    const int64_t rows_here = (a.M - m0 < kTileRows) ? a.M - m0 : kTileRows;      // multiple of 4 (padded layout)
+    const int n16 = (int)(rows_here * a.R / 4);
+    f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.T) + ((int64_t)chunk * a.trows + b * a.M + m0) * a.R);
+    const f32x4* src = reinterpret_cast<const f32x4*>(tl);
+    // streaming stores: plain (write-back) stores left dirty lines of T in L2 whose evictions cut into the read stream
+    // (5.1-5.8 ms per 2000^3 pass depending on where X and T lie; 4.8-5.2 ms with non-temporal stores)
+    for (int c = lane; c < n16; c += 64) __builtin_nontemporal_store(src[c], dst + c);
   }
 }
 
@@ -456,84 +447,215 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract_lead16_f32(LArg
 }
 
 // ---------------------------------------------------------------------------
-// f64 contraction (parity mode)
+// f64 contraction (parity mode): v_mfma_f64_16x16x4_f64, same structure as contract16_f32
 // ---------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void contract_f64(KArgs a) {
+//   A operand: lane (r2 = l&15, q = l>>4) holds A[row r2][k = q]; a lane's double2 load brings rows 32j + 2*r2 + v
+//   (v = 0, 1) of column c + q, so a wave owns 64 rows (j = 0, 1): 512 bytes per column, as in the fp32 kernel.
+//   B operand: lane (r2, q) holds F[c + q][16nt + r2].  C/D map of the f64 MFMA: col = l&15, tile row = (l>>4) + 4*reg.
+//   Leftover columns (R mod 16 in 1..4, R > 16: R = 20 is the headline rank) go to the vector pipe: lane (r2, q)
+//   multiplies its rows by F[c + q][16NT + e], e = 0..3 (v_fma_f64 runs at the MFMA's fp64 rate on this chip), the four
+//   k-quarters are added at the end.  A second, mostly empty MFMA tile doubled the matrix-pipe time: 6.5 ms of matrix
+//   work against an 8.1 ms HBM floor at 2000^3, R = 20 (round 1: 14.0 ms per pass).
+//   Register ring of three 8-column stages with the next stages' loads issued between MFMA groups (two stages, loads
+//   in front of the MFMA block, in the leftover-column form: three need 290 registers); the T tile is assembled in LDS
+//   and stored with coalesced streaming stores (see contract16_f32).  2000^3, R = 20: 10.1-10.3 ms per pass
+//   (6.3-6.4 TB/s algorithmic); MFMA tiles only with three stages: 10.2-10.3 ms (tools/micro/pass_f64.hip).
+static constexpr int kTileRows64 = 64;
+
+// main: frag[nt][g][lane] double2 = F[8g + 4e + (lane>>4)][16nt + (lane&15)], e = 0, 1
+// extra (after the main block): fe[g][e][q] double4 = F[8g + 4e + q][16NT + c], c = 0..3
+__global__ void pack_frag_f64(const double* __restrict__ F, int64_t ldF, int64_t C, int R, int NT, int EX,
+                              int64_t Cg, double* __restrict__ frag) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nmain = (int64_t)NT * Cg * 128;
+  if (idx < nmain) {
+    const int e = idx & 1;
+    const int lane = (idx >> 1) & 63;
+    const int64_t g = (idx >> 7) % Cg;
+    const int nt = (int)((idx >> 7) / Cg);
+    const int64_t c = 8 * g + 4 * e + (lane >> 4);
+    const int r = 16 * nt + (lane & 15);
+    frag[idx] = (c < C && r < R) ? F[c + ldF * r] : 0.0;
+  } else if (EX && idx < nmain + Cg * 32) {
+    const int64_t j = idx - nmain;
+    const int col = j & 3, q = (j >> 2) & 3, e = (j >> 4) & 1;
+    const int64_t g = j >> 5;
+    const int64_t c = 8 * g + 4 * e + q;
+    const int r = 16 * NT + col;
+    frag[idx] = (c < C && r < R) ? F[c + ldF * r] : 0.0;
+  }
+}
+
+template <int NT, bool EX>
+__global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract_f64(KArgs a) {
+  constexpr int RING = EX ? 2 : 3;                   // the leftover-column form has no registers for a third stage
   const int lane = threadIdx.x & 63;
   const int64_t wt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wt >= a.ntiles) return;
+  if (wt >= a.ntiles) return;                        // wave-uniform
   const int chunk = blockIdx.y;
   const int64_t b = wt / a.tiles_per_batch;
-  const int64_t m0 = (wt - b * a.tiles_per_batch) * kTileRows;
+  const int64_t m0 = (wt - b * a.tiles_per_batch) * kTileRows64;
   const int r2 = lane & 15, q = lane >> 4;
-  int64_t rowj[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    rowj[j] = m0 + 32 * j + 2 * r2;
-    if (rowj[j] >= a.M) rowj[j] = m0;
-  }
+  int64_t row0 = m0 + 2 * r2, row1 = m0 + 32 + 2 * r2;
+  if (row0 >= a.M) row0 = m0;                        // padding lanes re-read a valid row; never stored
+  if (row1 >= a.M) row1 = m0;
   const int64_t g0 = (int64_t)chunk * a.groups_per_chunk;
   int64_t g1 = g0 + a.groups_per_chunk;
   if (g1 > a.Cg) g1 = a.Cg;
-  const int64_t gfull = (a.C / kGroup < g1) ? a.C / kGroup : g1;
+  const int64_t gfull = (a.C / kGroup < g1) ? a.C / kGroup : g1;   // groups with all 8 columns valid
   const double* X = reinterpret_cast<const double*>(a.X) + b * a.batch_stride;
-  const f64x2* fbase = reinterpret_cast<const f64x2*>(a.frag);
-  const int64_t fnt = a.Cg * 64;
+  const double* xp0 = X + row0 + (kGroup * g0 + q) * a.ld;
+  const double* xp1 = X + row1 + (kGroup * g0 + q) * a.ld;
+  const int64_t ld4 = 4 * a.ld;
+  const f64x2* fp = reinterpret_cast<const f64x2*>(a.frag) + g0 * 64 + lane;
+  const int64_t fnt = a.Cg * 64;                     // double2 stride between N tiles
+  const f64x4* fe = reinterpret_cast<const f64x4*>(reinterpret_cast<const f64x2*>(a.frag) + (int64_t)NT * a.Cg * 64) + g0 * 8 + q;
 
-  f64x4 acc[4][2][NT];
+  f64x4 acc[NT][2][2];                               // [nt][j][v]
+  f64x4 accE[2][2];                                  // [j][v], the four leftover columns
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int v = 0; v < 2; ++v)
+    for (int v = 0; v < 2; ++v) {
+      accE[j][v] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][v][nt][i] = 0.0;
-
-  auto stage = [&](int64_t g, bool clamp) {
-    f64x2 x[2][4];
-    f64x2 f[NT];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      int64_t c = kGroup * g + 4 * e + q;
-      if (clamp && c >= a.C) c = a.C - 1;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) x[e][j] = *reinterpret_cast<const f64x2*>(X + rowj[j] + c * a.ld);
+      for (int nt = 0; nt < NT; ++nt) acc[nt][j][v] = f64x4{0.0, 0.0, 0.0, 0.0};
     }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) f[nt] = fbase[nt * fnt + g * 64 + lane];
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int v = 0; v < 2; ++v)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[j][v][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[e][j][v], f[nt][e], acc[j][v][nt], 0, 0, 0);
-  };
-#pragma unroll 2
-  for (int64_t g = g0; g < gfull; ++g) stage(g, false);
-  if (gfull < g1) stage(gfull, true);
 
-  // C/D map (f64!): col = lane&15, row rho = (lane>>4) + 4*reg ; tile row = 32j + 2*rho + v
-  double* Tc = reinterpret_cast<double*>(a.T) + ((int64_t)chunk * a.trows + b * a.M) * a.R;
+  // register ring of three 8-column stages; x index s = 2*e + j (e: column half of the group, j: row half of the tile)
+  f64x2 x0[4], x1[4], x2[4];
+  f64x4 e0[2], e1[2], e2[2];
+  f64x2 f0[NT], f1[NT], f2[NT];
+  const int64_t ng = gfull > g0 ? gfull - g0 : 0;
+  const int64_t gstep = kGroup * a.ld;
+#define AO_LOAD1(XS, GI, S)                                                                          \
+  XS[S] = __builtin_nontemporal_load(reinterpret_cast<const f64x2*>((((S) & 1) ? xp1 : xp0) + (GI) * gstep + ((S) >> 1) * ld4));
+#define AO_LOADF(FS, ES, GI)                                                                         \
+  {                                                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) FS[nt] = fp[(GI) * 64 + nt * fnt];            \
+    if (EX) { ES[0] = fe[(GI) * 8]; ES[1] = fe[(GI) * 8 + 4]; }                                      \
+  }
+#define AO_LOAD_STAGE(XS, FS, ES, GI)                                                                \
+  { AO_LOAD1(XS, GI, 0) AO_LOAD1(XS, GI, 1) AO_LOAD1(XS, GI, 2) AO_LOAD1(XS, GI, 3) AO_LOADF(FS, ES, GI) }
+#define AO_FMA_S(XS, FS, ES, S)                                                                      \
+  {                                                                                                  \
+    _Pragma("unroll") for (int v = 0; v < 2; ++v) {                                                  \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                              \
+        acc[nt][(S) & 1][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(XS[S][v], FS[nt][(S) >> 1], acc[nt][(S) & 1][v], 0, 0, 0); \
+      if (EX) {                                                                                      \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                \
+          accE[(S) & 1][v][c] = __builtin_fma(XS[S][v], ES[(S) >> 1][c], accE[(S) & 1][v][c]);       \
+      }                                                                                              \
+    }                                                                                                \
+  }
+#define AO_COMPUTE_STAGE(XS, FS, ES) { AO_FMA_S(XS, FS, ES, 0) AO_FMA_S(XS, FS, ES, 1) AO_FMA_S(XS, FS, ES, 2) AO_FMA_S(XS, FS, ES, 3) }
+#define AO_MIX_STAGE(XC, FC, EC, XL, FL, EL, GI)                                                     \
+  {                                                                                                  \
+    AO_FMA_S(XC, FC, EC, 0) AO_LOAD1(XL, GI, 0) __builtin_amdgcn_sched_barrier(0);                   \
+    AO_FMA_S(XC, FC, EC, 1) AO_LOAD1(XL, GI, 1) __builtin_amdgcn_sched_barrier(0);                   \
+    AO_FMA_S(XC, FC, EC, 2) AO_LOAD1(XL, GI, 2) __builtin_amdgcn_sched_barrier(0);                   \
+    AO_FMA_S(XC, FC, EC, 3) AO_LOAD1(XL, GI, 3) AO_LOADF(FL, EL, GI) __builtin_amdgcn_sched_barrier(0); \
+  }
+  int64_t g = 0;
+  if (RING == 3) {
+    if (ng > 0) AO_LOAD_STAGE(x0, f0, e0, 0)
+    if (ng > 1) AO_LOAD_STAGE(x1, f1, e1, 1)
+    for (; g + 5 <= ng; g += 3) {                    // steady state: every prefetch is in range
+      AO_MIX_STAGE(x0, f0, e0, x2, f2, e2, g + 2)
+      AO_MIX_STAGE(x1, f1, e1, x0, f0, e0, g + 3)
+      AO_MIX_STAGE(x2, f2, e2, x1, f1, e1, g + 4)
+    }
+    for (; g + 3 <= ng; g += 3) {                    // at most one drained round
+      if (g + 2 < ng) AO_LOAD_STAGE(x2, f2, e2, g + 2)
+      AO_COMPUTE_STAGE(x0, f0, e0)
+      if (g + 3 < ng) AO_LOAD_STAGE(x0, f0, e0, g + 3)
+      AO_COMPUTE_STAGE(x1, f1, e1)
+      if (g + 4 < ng) AO_LOAD_STAGE(x1, f1, e1, g + 4)
+      AO_COMPUTE_STAGE(x2, f2, e2)
+    }
+    if (g < ng) AO_COMPUTE_STAGE(x0, f0, e0)
+    if (g + 1 < ng) AO_COMPUTE_STAGE(x1, f1, e1)
+  } else {                                           // two stages: the leftover-column form has no room for a third
+    if (ng > 0) AO_LOAD_STAGE(x0, f0, e0, 0)
+    for (; g + 2 <= ng; g += 2) {
+      AO_LOAD_STAGE(x1, f1, e1, g + 1)
+      AO_COMPUTE_STAGE(x0, f0, e0)
+      if (g + 2 < ng) AO_LOAD_STAGE(x0, f0, e0, g + 2)
+      AO_COMPUTE_STAGE(x1, f1, e1)
+    }
+    if (g < ng) AO_COMPUTE_STAGE(x0, f0, e0)
+  }
+  g = gfull > g0 ? gfull : g0;
+  // ragged tail group: columns >= C are clamped (finite data) and meet zero B fragments
+  if (g < g1) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      int64_t c = kGroup * g + 4 * (s >> 1) + q;
+      if (c >= a.C) c = a.C - 1;
+      x0[s] = *reinterpret_cast<const f64x2*>(X + ((s & 1) ? row1 : row0) + c * a.ld);
+    }
+    {
+      const f64x2* fpt = reinterpret_cast<const f64x2*>(a.frag) + g * 64 + lane;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) f0[nt] = fpt[nt * fnt];
+      if (EX) {
+        const f64x4* fet = reinterpret_cast<const f64x4*>(reinterpret_cast<const f64x2*>(a.frag) + (int64_t)NT * a.Cg * 64) + g * 8 + q;
+        e0[0] = fet[0]; e0[1] = fet[4];
+      }
+    }
+    AO_COMPUTE_STAGE(x0, f0, e0)
+  }
+#undef AO_LOAD1
+#undef AO_LOADF
+#undef AO_LOAD_STAGE
+#undef AO_FMA_S
+#undef AO_COMPUTE_STAGE
+#undef AO_MIX_STAGE
+  // epilogue: C/D map of the f64 MFMA: col = lane&15, tile row rho = (lane>>4) + 4*reg; tile (j, v) row rho is
+  // unfolding row m0 + 32j + 2*rho + v.  The wave's 64 x R tile is assembled in its LDS slice and stored as whole lines.
+  extern __shared__ __attribute__((aligned(16))) double t_lds64[];
+  double* tl = t_lds64 + (threadIdx.x >> 6) * (kTileRows64 * a.R);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int r = 16 * nt + r2;
     if (r < a.R) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int rho = q + 4 * i;
-            const int64_t m = m0 + 32 * j + 2 * rho + v;
-            if (m < a.M) Tc[m * a.R + r] = acc[j][v][nt][i];
-          }
+          for (int i = 0; i < 4; ++i) tl[(32 * j + 2 * (q + 4 * i) + v) * a.R + r] = acc[nt][j][v][i];
     }
+  }
+  if (EX) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                 // add the four k-quarters; quarter 0 stores
+          double t = accE[j][v][c];
+          t += __shfl_xor(t, 16);
+          t += __shfl_xor(t, 32);
+          accE[j][v][c] = t;
+        }
+    if (q == 0) {
+      const int ne = a.R - 16 * NT;                  // 1..4 live extra columns
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c < ne) tl[(32 * j + 2 * r2 + v) * a.R + 16 * NT + c] = accE[j][v][c];
+    }
+  }
+  {
+    const int64_t rows_here = (a.M - m0 < kTileRows64) ? a.M - m0 : kTileRows64;   // multiple of 2 (padded layout)
+    const int n16 = (int)(rows_here * a.R / 2);
+    f64x2* dst = reinterpret_cast<f64x2*>(reinterpret_cast<double*>(a.T) + ((int64_t)chunk * a.trows + b * a.M + m0) * a.R);
+    const f64x2* src = reinterpret_cast<const f64x2*>(tl);
+    for (int c = lane; c < n16; c += 64) __builtin_nontemporal_store(src[c], dst + c);
   }
 }
 
@@ -544,6 +666,7 @@ static int nt_of(int R, int prec) {
   const int w = prec == AOADMM_PREC_F32 ? 32 : 16;
   return (R + w - 1) / w;
 }
+static int tile_rows(int prec) { return prec == AOADMM_PREC_F32 ? kTileRows : kTileRows64; }
 
 size_t ContractPlan::frag_bytes(int prec) const {
   const int64_t Cg = cdiv(C, kGroup);
@@ -557,7 +680,7 @@ ContractPlan make_plan(int64_t nbatch, int64_t batch_stride, int64_t M, int64_t 
   p.tprec = prec;
   p.nbatch = nbatch; p.batch_stride = batch_stride; p.M = M; p.ld = ld; p.C = C; p.R = R;
   const int64_t Cg = cdiv(C, kGroup);
-  const int64_t ntiles = nbatch * cdiv(M, kTileRows);
+  const int64_t ntiles = nbatch * cdiv(M, tile_rows(prec));
   int64_t nchunk = 1;
   // f32 accumulates in fp32 inside the MFMA: keep one accumulation run <= 2048 terms;
   // partial sums of different chunks are added in fp64 by the reduce kernels.
@@ -630,7 +753,7 @@ void launch_contract(const void* X, int prec, const ContractPlan& pl, const doub
   const int NT = nt_of(pl.R, prec);
   KArgs a;
   a.X = X; a.frag = frag_ws; a.T = T;
-  a.tiles_per_batch = cdiv(pl.M, kTileRows);
+  a.tiles_per_batch = cdiv(pl.M, tile_rows(prec));
   a.ntiles = pl.nbatch * a.tiles_per_batch;
   a.batch_stride = pl.batch_stride; a.M = pl.M; a.ld = pl.ld; a.C = pl.C; a.Cg = Cg;
   a.trows = pl.trows();
@@ -648,26 +771,37 @@ void launch_contract(const void* X, int prec, const ContractPlan& pl, const doub
     const int64_t total = (int64_t)nt16 * Cg * 128 + (ex ? Cg * 32 : 0);
     pack_frag16_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, nt16, ex ? 1 : 0, Cg, (float*)frag_ws);
     AO_KERNEL_CHECK();
-    if (ev0) AO_HIP(hipEventRecord(ev0, s));
-    if (nt16 == 1 && !ex) contract16_f32<1, false><<<grid, 256, 0, s>>>(a);
-    else if (nt16 == 1) contract16_f32<1, true><<<grid, 256, 0, s>>>(a);
-    else if (nt16 == 2 && !ex) contract16_f32<2, false><<<grid, 256, 0, s>>>(a);
-    else if (nt16 == 2) contract16_f32<2, true><<<grid, 256, 0, s>>>(a);
-    else if (nt16 == 3 && !ex) contract16_f32<3, false><<<grid, 256, 0, s>>>(a);
-    else if (nt16 == 3) contract16_f32<3, true><<<grid, 256, 0, s>>>(a);
-    else if (nt16 == 4) contract16_f32<4, false><<<grid, 256, 0, s>>>(a);
+    const size_t tsh = (size_t)4 * kTileRows * pl.R * sizeof(float);   // T tile of each of the four waves
+#define AO_GO(K) { if (tsh > 65536) ensure_dynamic_lds(reinterpret_cast<const void*>(K), (int)tsh); if (ev0) AO_HIP(hipEventRecord(ev0, s)); K<<<grid, 256, tsh, s>>>(a); }
+    if (nt16 == 1 && !ex) AO_GO((contract16_f32<1, false>))
+    else if (nt16 == 1) AO_GO((contract16_f32<1, true>))
+    else if (nt16 == 2 && !ex) AO_GO((contract16_f32<2, false>))
+    else if (nt16 == 2) AO_GO((contract16_f32<2, true>))
+    else if (nt16 == 3 && !ex) AO_GO((contract16_f32<3, false>))
+    else if (nt16 == 3) AO_GO((contract16_f32<3, true>))
+    else if (nt16 == 4) AO_GO((contract16_f32<4, false>))
     else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
+#undef AO_GO
   } else {
     AO_REQUIRE(pl.ld % 2 == 0 && pl.M % 2 == 0 && pl.batch_stride % 2 == 0, "f64 layout must be padded to 2");
-    int64_t total = (int64_t)NT * Cg * 128;
-    pack_frag_f64<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, NT, Cg, (double*)frag_ws);
+    // 16-column tiles; 1..4 leftover columns go to the vector pipe
+    const int rem = pl.R % 16;
+    const bool ex = pl.R > 16 && rem >= 1 && rem <= 4;
+    const int nt16 = ex ? pl.R / 16 : (pl.R + 15) / 16;
+    const int64_t total = (int64_t)nt16 * Cg * 128 + (ex ? Cg * 32 : 0);
+    pack_frag_f64<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, nt16, ex ? 1 : 0, Cg, (double*)frag_ws);
     AO_KERNEL_CHECK();
-    if (ev0) AO_HIP(hipEventRecord(ev0, s));
-    if (NT == 1) contract_f64<1><<<grid, 256, 0, s>>>(a);
-    else if (NT == 2) contract_f64<2><<<grid, 256, 0, s>>>(a);
-    else if (NT == 3) contract_f64<3><<<grid, 256, 0, s>>>(a);
-    else if (NT == 4) contract_f64<4><<<grid, 256, 0, s>>>(a);
+    const size_t tsh = (size_t)4 * kTileRows64 * pl.R * sizeof(double);   // T tile of each of the four waves
+#define AO_GO(K) { if (tsh > 65536) ensure_dynamic_lds(reinterpret_cast<const void*>(K), (int)tsh); if (ev0) AO_HIP(hipEventRecord(ev0, s)); K<<<grid, 256, tsh, s>>>(a); }
+    if (nt16 == 1 && !ex) AO_GO((contract_f64<1, false>))
+    else if (nt16 == 1) AO_GO((contract_f64<1, true>))
+    else if (nt16 == 2 && !ex) AO_GO((contract_f64<2, false>))
+    else if (nt16 == 2) AO_GO((contract_f64<2, true>))
+    else if (nt16 == 3 && !ex) AO_GO((contract_f64<3, false>))
+    else if (nt16 == 3) AO_GO((contract_f64<3, true>))
+    else if (nt16 == 4) AO_GO((contract_f64<4, false>))
     else throw Error(AOADMM_ERR_UNSUPPORTED, "rank > 64 not supported");
+#undef AO_GO
   }
   if (ev1) AO_HIP(hipEventRecord(ev1, s));
   AO_KERNEL_CHECK();
