@@ -623,7 +623,6 @@ __global__ void prox_tv_k(ColArgs a, int use_lds, const AdmmCtl* ctl) {
 // thread 0 falls back to the sequential scan, so the result is exact either way.  Inside the ADMM loop
 // J is warm-started from the previous Z column, which usually converges in 1-3 rounds.
 static constexpr int kTvParMax = 4096;
-static constexpr int kTvThreads = 256;
 
 // The iteration is built on prefix sums so that no step is sequential in a
 // segment's length: with Pc[i] = sum_{t<i} (y_t - c) (c = mean(y), which keeps the prefix sums small) the value
@@ -640,12 +639,17 @@ struct TvFused {
   double* part = nullptr;   // [R][4]: ||fac-Z||^2, ||fac||^2, ||mu||^2, ||Z-Zold||^2 of this column
   int64_t ld = 0;
 };
+// kTvThreads threads per column (256 for short columns, 1024 above 1024 rows: every phase walks a thread's chunk of
+// ceil(n / kTvThreads) entries sequentially through LDS, so four times the threads is close to four times fewer
+// dependent LDS round trips; measured at 2000 rows in DESIGN.md section 4.4).
+template <int kTvThreads>
 __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const double* warm, int64_t ldw, TvFused fz,
                                                              const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
+  constexpr int NW = kTvThreads / 64;
   extern __shared__ double dyn[];
-  __shared__ int wsum[4];
-  __shared__ double dsum[4];
+  __shared__ int wsum[NW];
+  __shared__ double dsum[NW];
   __shared__ int flag_merge, flag_split;
   const int n = (int)a.rows;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -683,7 +687,9 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
         if (i < n) { y[i] = ry[k]; val[i] = rw[k]; }
       }
     };
-    if (n <= 4 * kTvThreads) stage(std::integral_constant<int, 4>());
+    if (n <= kTvThreads) stage(std::integral_constant<int, 1>());
+    else if (n <= 2 * kTvThreads) stage(std::integral_constant<int, 2>());
+    else if (n <= 4 * kTvThreads) stage(std::integral_constant<int, 4>());
     else if (n <= 8 * kTvThreads) stage(std::integral_constant<int, 8>());
     else stage(std::integral_constant<int, kTvParMax / kTvThreads>());
   }
@@ -695,9 +701,10 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
     for (int off = 1; off < 64; off <<= 1) { const double u = __shfl_up(inc, off); if (lane >= off) inc += u; }
     if (lane == 63) dsum[w] = inc;
     __syncthreads();
-    double base = 0.0;
-    for (int q = 0; q < w; ++q) base += dsum[q];
-    total = dsum[0] + dsum[1] + dsum[2] + dsum[3];
+    double base = 0.0, all = 0.0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) { if (q < w) base += dsum[q]; all += dsum[q]; }
+    total = all;
     __syncthreads();
     return base + inc - v;
   };
@@ -744,7 +751,9 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
         for (int i = c0; i < c1; ++i)
           if (i == 0 || J[i - 1] != 0) start[pos++] = i;
       }
-      const int nseg = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      int nseg = 0;
+#pragma unroll
+      for (int q = 0; q < NW; ++q) nseg += wsum[q];
       if (t == 0) start[nseg] = n;
       __syncthreads();
       // 2. segment values
@@ -856,7 +865,9 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
       }
     }
   };
-  if (n <= 4 * kTvThreads) dual(std::integral_constant<int, 4>());
+  if (n <= kTvThreads) dual(std::integral_constant<int, 1>());
+  else if (n <= 2 * kTvThreads) dual(std::integral_constant<int, 2>());
+  else if (n <= 4 * kTvThreads) dual(std::integral_constant<int, 4>());
   else if (n <= 8 * kTvThreads) dual(std::integral_constant<int, 8>());
   else dual(std::integral_constant<int, kTvParMax / kTvThreads>());
   double q4[4] = {s1, s2, s3, s4};
@@ -866,7 +877,12 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if (lane == 0) dsum[w] = v;
     __syncthreads();
-    if (t == 0) fz.part[(int64_t)r * 4 + q] = (dsum[0] + dsum[1]) + (dsum[2] + dsum[3]);
+    if (t == 0) {
+      double tot4 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) tot4 += dsum[k];
+      fz.part[(int64_t)r * 4 + q] = tot4;
+    }
     __syncthreads();
   }
 }
@@ -1171,8 +1187,12 @@ size_t prox_ws_bytes(int type, int64_t rows, int R) {
 static size_t tv_fast_lds(int64_t rows) { return (size_t)(4 * rows + 2) * 8 + (size_t)(rows + 2) * 4 + (size_t)rows + 64; }
 static void tv_fast_launch(const ColArgs& a, const double* warm, int64_t ldw, const TvFused& fz, const AdmmCtl* ctl,
                            hipStream_t s) {
-  ensure_dynamic_lds(reinterpret_cast<const void*>(prox_tv_fast_k), (int)tv_fast_lds(kTvParMax));
-  prox_tv_fast_k<<<a.R, kTvThreads, tv_fast_lds(a.rows), s>>>(a, warm, ldw, fz, ctl);
+  if (a.rows > 1024) {
+    ensure_dynamic_lds(reinterpret_cast<const void*>(prox_tv_fast_k<1024>), (int)tv_fast_lds(kTvParMax));
+    prox_tv_fast_k<1024><<<a.R, 1024, tv_fast_lds(a.rows), s>>>(a, warm, ldw, fz, ctl);
+  } else {
+    prox_tv_fast_k<256><<<a.R, 256, tv_fast_lds(a.rows), s>>>(a, warm, ldw, fz, ctl);
+  }
   AO_KERNEL_CHECK();
 }
 
