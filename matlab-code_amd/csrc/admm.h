@@ -59,9 +59,17 @@ struct AdmmMode {
 int admm_partials(int64_t rows);
 // `deferred_end`: when given, the closing evaluation of the loop is not launched; the caller hands the
 // record to the next kernel it runs anyway (atb_small's `close`).
+// `gf` (optional): when the loop takes the two-launch row-local path its second launch also leaves the partial Gram
+// matrices of the new factor in gf->ws ([nb][R*R], nb returned) and the row-major copy in gf->At; the caller finishes
+// with atb_fin.  gf->nb stays 0 when the path was not taken.
+struct GramFold {
+  double* ws = nullptr;
+  double* At = nullptr;
+  int nb = 0;
+};
 void admm_constrained_loop(const AdmmMode& m, double* part, double* V, double* Znew, double* prox_ws,
                            AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du, hipStream_t s,
-                           LoopEnd* deferred_end = nullptr);
+                           LoopEnd* deferred_end = nullptr, GramFold* gf = nullptr);
 
 // generic pieces for the coupled / PARAFAC2 loops -------------------------------
 // (Z,mu) <- update_constraint (:1420-1429): Zold kept in `Zold`; slots[0..3] receive

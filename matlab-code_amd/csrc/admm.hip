@@ -285,6 +285,208 @@ __global__ __launch_bounds__(kRowBlock) void admm_rows_k(FusedArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// The whole inner loop of an element-wise-prox mode in TWO launches instead of MaxInnerIters, on the matrix cores.
+// With an element-wise prox every row of (fac, Z, mu) evolves on its own; only the residual test of the while
+// condition (:600) couples the rows.  Pass 1 (FINAL = false) runs all MaxInnerIters iterations for its 64 rows in
+// registers and stores nothing but the four residual partial sums of every iteration.  Pass 2 (FINAL = true) adds
+// the partial sums up (same data, same order in every block: same decision everywhere), finds the iteration k* after
+// which the reference loop stops, repeats exactly k* iterations -- the same instructions on the same operands, hence
+// the same bits -- and stores fac, Z, mu.  Block 0 records k* and the residuals of iteration k* in ctl.  Pass 2 also
+// leaves what the Gram kernel would compute next: the block's partial Gram matrix F_b'F_b and the row-major copy of
+// its rows of the factor (the caller adds the partials with atb_fin).
+//
+// The row solve fac = A_inner * inv(L*L') (:609) is computed transposed, fac' = Binv * A_inner' (Binv is symmetric),
+// with v_mfma_f64_16x16x4_f64: a wave owns 16 rows; lane (r = l&15, q = l>>4) supplies B[k = 4s+q][n = r] =
+// A_inner(row r, column 4s+q) and receives D[m = q+4i (+16mt)][n = r] = fac(row r, column 4(4mt+i)+q) -- the SAME
+// columns {4s+q} it supplies.  So a lane keeps A, Z, mu, fac of its row for the columns c = q (mod 4) in registers
+// for the whole loop and the element-wise prox and dual update are lane-local: no LDS exchange, no barrier inside
+// an iteration (the VALU form staged A_inner through LDS and read 20 + 100 LDS words per thread and iteration:
+// ~4 us per iteration at 2000 x 20 against ~0.4 us here).
+struct SpecExtra {
+  double* gram_ws;      // [gridDim.x][R*R] partial Gram matrices (FINAL only; may be null)
+  double* At;           // rows x R row-major copy of fac (FINAL only; may be null)
+};
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
+static constexpr int kSpecMaxInner = 10;      // beyond this the work thrown away after an early exit could matter
+static constexpr int kSpecThreads = 64;       // one wave = 16 rows per workgroup: no barrier anywhere in the kernel
+static constexpr int kSpecPartJ = 4;          // a lane adds up to 4 partial sums per iteration: <= 256 workgroups
+template <int KS, bool FINAL>
+__global__ __launch_bounds__(kSpecThreads) void admm_rows_mfma_k(FusedArgs a, SpecExtra ex) {
+  constexpr int MT = (KS + 3) / 4;
+  extern __shared__ double rsh[];                   // FINAL: [16][RP] tile of the new factor for the Gram partial
+  const int R = a.R;
+  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + r;
+  const bool have = i < a.rows;
+  const int nparts = gridDim.x;
+  double av[KS], mu[KS], zo[KS], x[KS], bi[MT][KS];
+  // every global load of the kernel in one round trip, on clamped (always valid) addresses
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int c = 4 * s + q;
+    const int64_t o = (have ? i : a.rows - 1) + a.rows * (c < R ? c : 0);
+    zo[s] = a.Z[o]; mu[s] = a.mu[o]; av[s] = a.A[o];
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int m = 16 * mt + r, k = 4 * s + q;
+      bi[mt][s] = a.Binv[(m < R ? m : 0) + R * (k < R ? k : 0)];
+    }
+  const double rho = a.rho[0];
+  int niter = a.max_inner;
+  if (FINAL) {
+    // k*: the first iteration whose residuals end the loop (eval_res_ADMM_constr :1079-1096, while condition :600).
+    // Branch-free loads (clamped indices, masked adds) so that all of them are in flight together.
+    double S[kSpecMaxInner][4];
+#pragma unroll
+    for (int it = 0; it < kSpecMaxInner; ++it) {
+      const int itc = it < a.max_inner ? it : a.max_inner - 1;
+      double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+      for (int j = 0; j < kSpecPartJ; ++j) {
+        const int b = lane + 64 * j;
+        const bool ok = b < nparts;
+        const f64x4_t v = *reinterpret_cast<const f64x4_t*>(a.part + ((int64_t)itc * nparts + (ok ? b : 0)) * 4);
+        s0 += ok ? v[0] : 0.0; s1 += ok ? v[1] : 0.0; s2 += ok ? v[2] : 0.0; s3 += ok ? v[3] : 0.0;
+      }
+      S[it][0] = s0; S[it][1] = s1; S[it][2] = s2; S[it][3] = s3;
+    }
+    double pr = 0.0, du = 0.0;
+    int ks = a.max_inner;
+    bool found = false;
+#pragma unroll
+    for (int it = 1; it <= kSpecMaxInner; ++it) {
+      double s0 = S[it - 1][0], s1 = S[it - 1][1], s2 = S[it - 1][2], s3 = S[it - 1][3];
+      for (int off = 32; off > 0; off >>= 1) {       // butterfly: every lane ends with the same total
+        s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off);
+        s2 += __shfl_xor(s2, off); s3 += __shfl_xor(s3, off);
+      }
+      if (!found && it <= a.max_inner) {
+        pr = sqrt(s0) / sqrt(s1);                                            // :1085
+        const double sc = sqrt(s2);
+        du = sc > 0 ? sqrt(s3) / sc : sqrt(s3);                              // :1087-1092
+        if (!(it < a.max_inner && (pr > a.tol_pr || du > a.tol_du))) { ks = it; found = true; }
+      }
+    }
+    niter = ks;
+    if (blockIdx.x == 0 && lane == 0) {
+      a.ctl->res[1] = pr;
+      a.ctl->res[3] = du;
+      a.ctl->iters = ks;
+      a.ctl->active = 0;
+    }
+  }
+  // padding columns (4s+q >= R) and padding rows of Binv carry zeros: they add nothing to the products
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (4 * s + q >= R) { av[s] = 0.0; zo[s] = 0.0; mu[s] = 0.0; }
+    x[s] = 0.0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      if (16 * mt + r >= R || 4 * s + q >= R) bi[mt][s] = 0.0;
+  }
+  const double rh = rho / 2;
+  const ElemProx ep = elem_prox_of(a.ptype, a.p0, a.p1, rho);
+  for (int it = 0; it < niter; ++it) {
+    double ain[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) ain[s] = av[s] + rh * (zo[s] - mu[s]);       // A_inner = A + rho/2*(Z - mu)   (:608)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {                                          // fac = A_inner * inv(L*L')       (:609)
+      f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[mt][s], ain[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (4 * mt + e < KS) x[4 * mt + e] = acc[e];
+    }
+    double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const double z = elem_prox(ep, x[s] + mu[s]);                            // Z = prox(fac + mu)              (:1425)
+      const double mn = mu[s] + x[s] - z;                                      // mu = mu + fac - Z               (:1428)
+      if (have && 4 * s + q < R) {
+        const double d = x[s] - z;
+        s1 += d * d;
+        s2 += x[s] * x[s];
+        s3 += mn * mn;
+        const double e = z - zo[s];
+        s4 += e * e;
+        mu[s] = mn;
+        zo[s] = z;
+      }
+    }
+    if (!FINAL) {
+      for (int off = 32; off > 0; off >>= 1) {      // fixed-order wave tree
+        s1 += __shfl_down(s1, off);
+        s2 += __shfl_down(s2, off);
+        s3 += __shfl_down(s3, off);
+        s4 += __shfl_down(s4, off);
+      }
+      if (lane == 0) {
+        f64x4_t v = {s1, s2, s3, s4};
+        *reinterpret_cast<f64x4_t*>(a.part + ((int64_t)it * nparts + blockIdx.x) * 4) = v;
+      }
+    }
+  }
+  if (!FINAL) return;
+  if (have) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int c = 4 * s + q;
+      if (c < R) {
+        const int64_t o = i + a.rows * c;
+        a.fac[o] = x[s];
+        a.Z[o] = zo[s];
+        a.mu[o] = mu[s];
+      }
+    }
+  }
+  if (ex.gram_ws == nullptr) return;
+  // Row-major copy of the wave's 16 rows and their partial Gram matrix G_b = F_b'F_b (what atb_part_k would do
+  // next).  The tile goes through the wave's LDS (a wave's LDS operations complete in order: no barrier); the Gram
+  // partial is MFMA work as well: D[m][n] = sum_k F(k, m) F(k, n) with the 16 rows as the reduction index.
+  const int RP = R | 1;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int c = 4 * s + q;
+    if (c < R) rsh[r * RP + c] = have ? x[s] : 0.0;
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int nr = (int)((a.rows - r0 < 16) ? (a.rows - r0) : 16);
+  if (ex.At)
+    for (int e = lane; e < nr * R; e += kSpecThreads) {
+      const int ii = e / R, k = e - ii * R;
+      ex.At[(r0 + ii) * R + k] = rsh[ii * RP + k];
+    }
+  double fo[MT][4];                                   // F(row 4s + q, column 16mt + r), s = 0..3
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int c = 16 * mt + r;
+      fo[mt][s] = c < R ? rsh[(4 * s + q) * RP + c] : 0.0;
+    }
+  double* G = ex.gram_ws + (int64_t)blockIdx.x * R * R;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < MT; ++nt) {
+      f64x4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fo[mt][s], fo[nt][s], acc, 0, 0, 0);
+      const int n = 16 * nt + r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = 16 * mt + q + 4 * e;
+        if (m < R && n < R) G[m + R * n] = acc[e];
+      }
+    }
+}
+
 // Thread-per-row variant for the triangular-solve path (no explicit inverse available: op-level entry)
 template <int RMAX>
 __global__ __launch_bounds__(kRowThreads) void admm_rowL_k(FusedArgs a) {
@@ -1265,6 +1467,22 @@ static void launch_rows(const FusedArgs& a, unsigned blocks, hipStream_t s) {
   if (a.R == 4 * CPW) admm_rows_k<CPW, true><<<blocks, kRowBlock, sh, s>>>(a);
   else admm_rows_k<CPW, false><<<blocks, kRowBlock, sh, s>>>(a);
 }
+template <int KS>
+static void launch_rows_mfma(const FusedArgs& a, const SpecExtra& ex, bool fin, unsigned blocks, hipStream_t s) {
+  const size_t sh = fin ? (size_t)16 * (a.R | 1) * sizeof(double) : 0;
+  if (fin) admm_rows_mfma_k<KS, true><<<blocks, kSpecThreads, sh, s>>>(a, ex);
+  else admm_rows_mfma_k<KS, false><<<blocks, kSpecThreads, sh, s>>>(a, ex);
+}
+static void launch_rows_mfma_any(const FusedArgs& a, const SpecExtra& ex, bool fin, unsigned blocks, hipStream_t s) {
+  const int need = (a.R + 3) / 4;
+  if (need <= 1) launch_rows_mfma<1>(a, ex, fin, blocks, s);
+  else if (need <= 2) launch_rows_mfma<2>(a, ex, fin, blocks, s);
+  else if (need <= 3) launch_rows_mfma<3>(a, ex, fin, blocks, s);
+  else if (need <= 4) launch_rows_mfma<4>(a, ex, fin, blocks, s);
+  else if (need <= 5) launch_rows_mfma<5>(a, ex, fin, blocks, s);
+  else if (need <= 6) launch_rows_mfma<6>(a, ex, fin, blocks, s);
+  else launch_rows_mfma<8>(a, ex, fin, blocks, s);
+}
 static void launch_row_iteration(const FusedArgs& a, unsigned blocks, hipStream_t s) {
   if (a.Binv) {
     const int need = (a.R + 3) / 4;
@@ -1288,7 +1506,7 @@ static void launch_row_iteration(const FusedArgs& a, unsigned blocks, hipStream_
 
 void admm_constrained_loop(const AdmmMode& m, double* part, double* V, double* Znew, double* prox_ws,
                            AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du, hipStream_t s,
-                           LoopEnd* deferred_end) {
+                           LoopEnd* deferred_end, GramFold* gf) {
   FusedArgs a;
   a.A = m.A; a.L = m.L; a.Binv = m.Binv; a.rho = m.rho; a.fac = m.fac; a.Z = m.Z; a.mu = m.mu; a.V = V; a.part = part;
   a.ctl = ctl;
@@ -1301,6 +1519,19 @@ void admm_constrained_loop(const AdmmMode& m, double* part, double* V, double* Z
   const int64_t n = m.rows * m.R;
   int64_t nbd = cdiv(n, 1024);
   if (nbd > 64) nbd = 64;
+  // element-wise prox: the whole loop in two launches (admm_rows_mfma_k)
+  const int64_t tiles = cdiv(m.rows, 16);            // one wave per 16 rows
+  if (a.fused && a.ptype != AOADMM_C_SIMPLEX_ROW && a.Binv && a.R <= 32 && tiles <= 64 * kSpecPartJ &&
+      max_inner <= kSpecMaxInner && (int64_t)max_inner * tiles <= 2 * kMaxParts) {
+    SpecExtra ex{nullptr, nullptr};
+    launch_rows_mfma_any(a, ex, false, (unsigned)tiles, s);
+    AO_KERNEL_CHECK();
+    if (gf && gf->ws) { ex.gram_ws = gf->ws; ex.At = gf->At; gf->nb = (int)tiles; }
+    launch_rows_mfma_any(a, ex, true, (unsigned)tiles, s);
+    AO_KERNEL_CHECK();
+    if (deferred_end) *deferred_end = LoopEnd();    // the loop is closed: pass 2 recorded iters / residuals
+    return;
+  }
   const bool tv_fused = !a.fused && m.prox.type == AOADMM_C_TV && m.rows <= kTvParMax;   // prox + dual in one kernel
   const int nparts = a.fused ? (int)blocks : (tv_fused ? m.R : (int)nbd);
   for (int it = 0; it < max_inner; ++it) {

@@ -43,6 +43,8 @@ struct LoopEnd;
 void atb_small(double* out, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t I,
                int K, int N, double* ws, const AdmmCtl* ctl, hipStream_t s, double* At_rowmajor = nullptr,
                const LoopEnd* close = nullptr);
+// out = sum of nb partial K x N matrices left in ws by a producer other than atb_part_k (fixed order)
+void atb_fin(double* out, const double* ws, int nb, int KN, const AdmmCtl* ctl, hipStream_t s);
 // slot[0] = sum (x-y)^2 (y may be null) ; ws >= 64 doubles
 void sumsq_diff(double* slot, const double* x, const double* y, int64_t n, double* ws,
                 const AdmmCtl* ctl, hipStream_t s);

@@ -171,6 +171,11 @@ void atb_small(double* out, const double* A, int64_t lda, const double* B, int64
   AO_KERNEL_CHECK();
 }
 
+void atb_fin(double* out, const double* ws, int nb, int KN, const AdmmCtl* ctl, hipStream_t s) {
+  atb_fin_k<<<(unsigned)cdiv(KN, 32), 256, 0, s>>>(out, ws, nb, KN, ctl);
+  AO_KERNEL_CHECK();
+}
+
 // ---------------------------------------------------------------------------
 // batch of independent reductions in one launch (the objective evaluation needs ~10 of them per outer
 // iteration; one kernel each was ~10 us of latency apiece).  grid = (nsplit, ntasks); fixed summation order.

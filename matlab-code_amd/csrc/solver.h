@@ -211,7 +211,7 @@ class Engine {
   bool ensure_permuted_copy(CpBlock& b);
   bool ensure_permuted_copy2(CpBlock& b);
   void drop_permuted_copies(CpBlock& b);
-  void prefetch_next_contraction(const aoadmm_options& opt);
+  bool prefetch_next_contraction(const aoadmm_options& opt);   // true: a tensor pass was enqueued
   // `collective` = false: the block holds the whole tensor and the result is complete on this engine (op-level
   // entry on an engine that happens to belong to a communicator)
   void block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
@@ -248,6 +248,8 @@ class Engine {
 
   int device_ = 0;
   hipStream_t stream_ = nullptr;
+  hipStream_t side_ = nullptr;        // objective evaluation beside the prefetched tensor pass (Engine::solve)
+  hipEvent_t side_ev_ = nullptr;
   int n_modes_ = 0, n_tensors_ = 0, n_couplings_ = 0;
   bool model_done_ = false;
   bool has_ridge_ = false;

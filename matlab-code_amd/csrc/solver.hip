@@ -39,6 +39,8 @@ Engine::Engine(int device) : device_(device) {
   if (device < 0 || device >= n) throw Error(AOADMM_ERR_INVALID, fmt("device %d out of range [0,%d)", device, n));
   AO_HIP(hipSetDevice(device));
   AO_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  AO_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+  AO_HIP(hipEventCreateWithFlags(&side_ev_, hipEventDisableTiming));
   redws_.alloc(4096 * sizeof(double));
   ones_.alloc(sizeof(double));
   const double one = 1.0;
@@ -50,6 +52,8 @@ Engine::~Engine() {
   for (auto& ks : kstats_)
     for (auto& pr : ks.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   if (comm_) (void)ncclCommDestroy(comm_);
+  if (side_ev_) (void)hipEventDestroy(side_ev_);
+  if (side_) (void)hipStreamDestroy(side_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -989,25 +993,27 @@ void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int 
 
 // The first tensor pass of the next outer iteration does not depend on the host's stopping decision, so
 // it is enqueued before the host waits for the objective values: the round trip hides behind it.
-void Engine::prefetch_next_contraction(const aoadmm_options& opt) {
-  if (!opt.use_dimtree) return;
+bool Engine::prefetch_next_contraction(const aoadmm_options& opt) {
+  if (!opt.use_dimtree) return false;
   for (int cid = -1; cid < n_couplings_; ++cid) {
     for (int p = 0; p < n_tensors_; ++p)
       for (int m = 0; m < n_modes_; ++m) {
         const ModeInfo& mi = modes_[m];
         if (mi.coupling != cid || mi.tensor != p) continue;
         TensorInfo& t = tensors_[p];                      // first mode the next iteration updates
-        if (t.par2 || t.blk.nd != 3) return;
+        if (t.par2 || t.blk.nd != 3) return false;
         FactorRef facs[8];
         for (int i = 0; i < t.nmodes; ++i) {
           const ModeInfo& o = modes_[t.modes[i]];
           facs[i] = factor_ref(o);
         }
         std::vector<int> seq = update_sequence(p);
+        const int64_t before = kstats_[0].launches + kstats_[1].launches;
         ensure_contraction(t.blk, mi.pos, facs, mi.R, true, seq.data(), (int)seq.size());
-        return;
+        return kstats_[0].launches + kstats_[1].launches > before;     // false: the cached pass still serves
       }
   }
+  return false;
 }
 
 void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
@@ -1223,6 +1229,7 @@ void Engine::update_uncoupled_cp_mode(int m, const aoadmm_options& opt) {
   prepare_mode_system(m, mi.constrained ? 1 : 0, opt);
   AdmmCtl* ctl = ctl_of_mode(m);
   LoopEnd le;
+  GramFold gf;
   if (!mi.constrained) {
     // G.fac{m} = A{m}/B{m}  (:134): B is symmetric positive definite -> Cholesky solve
     row_solve(mi.fac.d(), mi.rows, mi.Aeff, mi.rows, mi.L.d(), mi.rows, mi.R, nullptr, stream_);
@@ -1231,11 +1238,19 @@ void Engine::update_uncoupled_cp_mode(int m, const aoadmm_options& opt) {
     am.A = mi.Aeff; am.L = mi.L.d(); am.Binv = mi.Binv.d(); am.rho = mi.rho.d();
     am.fac = mi.fac.d(); am.Z = mi.Z.d(); am.mu = mi.mu.d();
     am.rows = mi.rows; am.R = mi.R; am.prox = mi.prox;
+    mi.facT.ensure((size_t)mi.rows * mi.R * sizeof(double));
+    atbws_.ensure((size_t)cdiv(mi.rows, 16) * mi.R * mi.R * sizeof(double));
+    gf.ws = atbws_.d(); gf.At = mi.facT.d();
     admm_constrained_loop(am, mi.part.d(), mi.V.d(), mi.Znew.d(), mi.proxws.d(), ctl, opt.MaxInnerIters,
-                          opt.innerRelPrTol_constr, opt.innerRelDualTol_constr, stream_, &le);
+                          opt.innerRelPrTol_constr, opt.innerRelDualTol_constr, stream_, &le, &gf);
   }
   mi.version++;
-  compute_gram(mi, le.ctl ? &le : nullptr);                                   // :148
+  if (gf.nb > 0) {                                                            // :148, partials left by the loop's last launch
+    atb_fin(mi.gram.d(), atbws_.d(), gf.nb, mi.R * mi.R, nullptr, stream_);
+    mi.facT_version = mi.version;
+  } else {
+    compute_gram(mi, le.ctl ? &le : nullptr);                                 // :148
+  }
 }
 
 // The six linear couplings (cmtf_fun_AOADMM.m:625-1075) in one form:  Tf_m(C_m) = Sd_m(Delta)
@@ -2238,9 +2253,30 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
       for (int p = 0; p < n_tensors_; ++p)
         if (tensors_[p].par2 ? tensors_[p].p2.has_mask : tensors_[p].blk.has_mask) em_pass_enqueue(p, 1);
     for (int i = 0; i < 4; ++i) fo[i] = f[i];
-    eval_objective_enqueue(false);                                             // :447
-    enqueue_readback();
-    if (iter < opt.MaxOuterIters) prefetch_next_contraction(opt);
+    if (iter < opt.MaxOuterIters) {
+      // The objective needs nothing the first tensor pass of the next iteration writes (frag, T), and that pass does
+      // not depend on the stopping decision: the pass goes onto the main stream, the objective kernels and their
+      // read-back onto the side stream behind an event, and the main stream takes up its small kernels again only
+      // when the objective is through (they overwrite what it reads).  ~50 us per iteration off the critical path.
+      // (Only when a pass is actually launched: the cross-stream wait alone costs ~40 us.)
+      AO_HIP(hipEventRecord(side_ev_, stream_));
+      if (prefetch_next_contraction(opt)) {
+        AO_HIP(hipStreamWaitEvent(side_, side_ev_, 0));
+        std::swap(stream_, side_);
+        try {
+          eval_objective_enqueue(false);                                       // :447
+          enqueue_readback();
+        } catch (...) { std::swap(stream_, side_); throw; }
+        std::swap(stream_, side_);
+        AO_HIP(hipStreamWaitEvent(stream_, pin.ev, 0));
+      } else {
+        eval_objective_enqueue(false);                                         // :447
+        enqueue_readback();
+      }
+    } else {
+      eval_objective_enqueue(false);                                           // :447
+      enqueue_readback();
+    }
     finish_eval(f);
     if (out->func_val_conv) out->func_val_conv[iter] = f[0];
     if (out->func_coupl_conv) out->func_coupl_conv[iter] = f[1];
