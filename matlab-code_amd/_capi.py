@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libaoadmm_hip.so')
+LIB_PATH = os.environ.get('AOADMM_LIB_PATH') or os.path.join(_HERE, 'libaoadmm_hip.so')   # the override is for A/B timing of builds
 
 # status codes (include/aoadmm_hip.h)
 OK, ERR_INVALID, ERR_HIP, ERR_NOT_PD, ERR_RCCL, ERR_UNSUPPORTED, ERR_NOMEM = range(7)

@@ -27,6 +27,15 @@ struct QuadPrep {
   void attach(ProxSpec& ps) const { ps.Lmat = L.d(); ps.LU = U.d(); ps.LUt = Ut.d(); ps.Lw = w.d(); }
 };
 
+// iso.hip: workgroup-parallel isotonic / unimodal projections and the path-Laplacian smoothness prox
+// mode 0: non-decreasing, 1: non-increasing, 2: unimodal (nonneg != 0: with projection onto x >= 0)
+size_t iso_ws_bytes(int64_t rows, int R);
+void prox_iso(const double* V, int64_t ldv, double* Z, int64_t ldz, int64_t rows, int R, int mode, double nonneg,
+              double* ws, const AdmmCtl* ctl, hipStream_t s);
+// false: the column is too long for the LDS-resident cyclic reduction (the caller solves sequentially)
+bool prox_gl_pcr(const double* V, int64_t ldv, double* Z, int64_t ldz, int64_t rows, int R, double eta, const double* rho,
+                 double rho_mul, const AdmmCtl* ctl, hipStream_t s);
+
 bool prox_is_fusable(int type);
 // constraints with a reg_func entry (constraints_to_prox.m): their value enters f_tensors (cmtf_fun_AOADMM.m:1272-1288)
 inline bool prox_has_reg_value(int t) {

@@ -1089,129 +1089,9 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
   }
 }
 
-// isotonic regression (PAVA), non-decreasing; `sign` = -1 gives -project_monotone(-x) (:26,:28)
-__global__ void prox_monotone_k(ColArgs a, double sign, const AdmmCtl* ctl) {
-  CTL_GUARD(ctl);
-  if (threadIdx.x != 0) return;
-  const int r = blockIdx.x;
-  const int64_t n = a.rows;
-  const double* v = a.V + a.ldv * r;
-  double* z = a.Z + a.ldz * r;
-  double* val = a.ws + (int64_t)r * 3 * n;
-  double* wt = val + n;
-  double* len = wt + n;
-  int64_t nb = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    val[nb] = sign * v[i];
-    wt[nb] = 1.0;
-    len[nb] = 1.0;
-    ++nb;
-    while (nb > 1 && val[nb - 2] > val[nb - 1]) {
-      const double w = wt[nb - 2] + wt[nb - 1];
-      val[nb - 2] = (val[nb - 2] * wt[nb - 2] + val[nb - 1] * wt[nb - 1]) / w;
-      wt[nb - 2] = w;
-      len[nb - 2] += len[nb - 1];
-      --nb;
-    }
-  }
-  int64_t o = 0;
-  for (int64_t b = 0; b < nb; ++b) {
-    const int64_t L = (int64_t)len[b];
-    for (int64_t t = 0; t < L; ++t) z[o++] = sign * val[b];
-  }
-}
+// isotonic / unimodal projections and the parallel GL solve live in iso.hip
 
-// unimodal regression: functions/project_unimodal_vector.m (Stout 2008).  Two threads run the
-// prefix isotonic regressions (:11,:12); thread 0 picks the split (:21-32) and rebuilds (:34-41).
-// All arrays keep MATLAB's 1-based indexing (slot 0 unused).
-__device__ void prefix_isotonic_dev(const double* y, int64_t n, bool flip, bool nonneg, double* sumwy,
-                                    double* sumwy2, double* sumw, double* level, double* idxr,
-                                    double* err, double* cums, double* thr) {
-  // y accessed as y(i) = flip ? y[n-i] : y[i-1], i = 1..n
-  sumwy[1] = 0; sumwy2[1] = 0; sumw[1] = 0;
-  level[1] = -INFINITY; idxr[1] = 0; err[1] = 0;
-  double run = 0.0;
-  cums[1] = 0.0;
-  for (int64_t i = 2; i <= n + 1; ++i) {
-    const double yi = flip ? y[n - (i - 1)] : y[i - 2];
-    sumwy[i] = yi; sumwy2[i] = yi * yi; sumw[i] = 1.0;
-    run += yi * yi;
-    cums[i] = run;                                   // cumsum(sumwy2) (:56)
-    thr[i] = 0.0;
-  }
-  for (int64_t i = 2; i <= n + 1; ++i) {
-    level[i] = sumwy[i];                             // y(i-1) (:61)
-    int64_t ir = i;                                  // :62
-    while (level[i] <= level[ir - 1]) {              // :63
-      const int64_t mg = ir - 1;
-      sumwy[i] += sumwy[mg];                         // :83-86
-      sumwy2[i] += sumwy2[mg];
-      sumw[i] += sumw[mg];
-      level[i] = sumwy[i] / sumw[i];
-      ir = (int64_t)idxr[ir - 1];                    // :65
-    }
-    idxr[i] = (double)ir;
-    const double levelerror = sumwy2[i] - (sumwy[i] * sumwy[i] / sumw[i]);   // :67
-    if (nonneg && level[i] < 0) {
-      thr[i] = 1.0;
-      err[i] = cums[i - 1];                          // :70
-    } else {
-      err[i] = levelerror + err[ir - 1];             // :72
-    }
-  }
-  if (nonneg)
-    for (int64_t i = 2; i <= n + 1; ++i)
-      if (thr[i] != 0.0) level[i] = 0.0;             // :76
-}
-
-__global__ void prox_unimodal_k(ColArgs a, const AdmmCtl* ctl) {
-  CTL_GUARD(ctl);
-  const int r = blockIdx.x;
-  const int64_t n = a.rows;
-  const double* v = a.V + a.ldv * r;
-  double* z = a.Z + a.ldz * r;
-  const int64_t st = n + 2;
-  double* base = a.ws + (int64_t)r * 16 * st;
-  const bool nonneg = a.p0 != 0.0;
-  if (threadIdx.x < 2) {
-    double* b = base + (int64_t)threadIdx.x * 8 * st;
-    prefix_isotonic_dev(v, n, threadIdx.x == 1, nonneg, b, b + st, b + 2 * st, b + 3 * st, b + 4 * st,
-                        b + 5 * st, b + 6 * st, b + 7 * st);
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  const double* lvlL = base + 3 * st;  const double* idxL = base + 4 * st;  const double* errL = base + 5 * st;
-  const double* lvlR = base + 8 * st + 3 * st;  const double* idxR = base + 8 * st + 4 * st;
-  const double* errR = base + 8 * st + 5 * st;
-  // returned arrays of the reference are the slots 2..n+1 -> element t (1-based) is slot t+1;
-  // iso(:,2) = index_range(2:end)-1
-  double best = errR[n + 1];                                    // error_right(end)  (:22)
-  int64_t best_idx = 1;
-  for (int64_t i = 2; i <= n; ++i) {                            // :24-30
-    const double e = errL[i + 1] + errR[(n - (i - 1)) + 1];
-    if (e < best) { best = e; best_idx = i; }
-  }
-  // left part: positions 1..best_idx  (:15, :34-41)
-  {
-    int64_t idx = best_idx;
-    while (idx >= 1) {
-      const int64_t lo = (int64_t)idxL[idx + 1] - 1;
-      for (int64_t t = lo; t <= idx; ++t) z[t - 1] = lvlL[idx + 1];
-      idx = lo - 1;
-    }
-  }
-  // right part: mode_idx = n - best_idx on the flipped vector, written back flipped (:16,:18)
-  {
-    const int64_t mlen = n - best_idx;
-    int64_t idx = mlen;
-    while (idx >= 1) {
-      const int64_t lo = (int64_t)idxR[idx + 1] - 1;
-      for (int64_t t = lo; t <= idx; ++t) z[n - t] = lvlR[idx + 1];   // flip: element t of the flipped part
-      idx = lo - 1;
-    }
-  }
-}
-
+// GL smoothness on columns longer than the cyclic-reduction kernel of iso.hip takes: one thread per column
 // GL smoothness: (2*eta/rho*L + I) \ x with the path-graph Laplacian (:68-76): Thomas algorithm
 __global__ void prox_gl_k(ColArgs a, const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
@@ -1377,8 +1257,8 @@ static constexpr int64_t kTvLdsRows = 8192;
 size_t prox_ws_bytes(int type, int64_t rows, int R) {
   switch (type) {
     case AOADMM_C_NONDECREASING:
-    case AOADMM_C_NONINCREASING: return (size_t)R * 3 * rows * sizeof(double);
-    case AOADMM_C_UNIMODAL: return (size_t)R * 16 * (rows + 2) * sizeof(double);
+    case AOADMM_C_NONINCREASING:
+    case AOADMM_C_UNIMODAL: return iso_ws_bytes(rows, R);
     case AOADMM_C_GL_SMOOTH: return (size_t)R * rows * sizeof(double);
     case AOADMM_C_ORTHONORMAL: return (size_t)R * rows * sizeof(double);
     case AOADMM_C_QUADRATIC: return (size_t)R * rows * sizeof(double);
@@ -1432,10 +1312,12 @@ void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, 
       prox_tv_k<<<R, 64, sh, s>>>(a, use_lds, ctl);
       break;
     }
-    case AOADMM_C_NONDECREASING: prox_monotone_k<<<R, 64, 0, s>>>(a, 1.0, ctl); break;
-    case AOADMM_C_NONINCREASING: prox_monotone_k<<<R, 64, 0, s>>>(a, -1.0, ctl); break;
-    case AOADMM_C_UNIMODAL: prox_unimodal_k<<<R, 64, 0, s>>>(a, ctl); break;
-    case AOADMM_C_GL_SMOOTH: prox_gl_k<<<R, 64, 0, s>>>(a, ctl); break;
+    case AOADMM_C_NONDECREASING: prox_iso(V, ldv, Zout, ldz, rows, R, 0, 0.0, ws, ctl, s); break;
+    case AOADMM_C_NONINCREASING: prox_iso(V, ldv, Zout, ldz, rows, R, 1, 0.0, ws, ctl, s); break;
+    case AOADMM_C_UNIMODAL: prox_iso(V, ldv, Zout, ldz, rows, R, 2, ps.p0, ws, ctl, s); break;
+    case AOADMM_C_GL_SMOOTH:
+      if (!prox_gl_pcr(V, ldv, Zout, ldz, rows, R, ps.p0, rho_dev, rho_mul, ctl, s)) prox_gl_k<<<R, 64, 0, s>>>(a, ctl);
+      break;
     case AOADMM_C_ORTHONORMAL: prox_ortho_k<<<1, 256, (size_t)R * R * sizeof(double), s>>>(a, ctl); break;
     case AOADMM_C_QUADRATIC: {                       // (2*eta/rho*L + I) \ x = U diag(1/(2 eta/rho w + 1)) U' x   (:66)
       AO_REQUIRE(ps.LU && ps.LUt && ps.Lw, "quadratic regularization: matrix not prepared");

@@ -76,6 +76,45 @@ def test_prox_matches_oracle(eng, c, shape):
     assert rel_fro(got, ref) < 1e-10 or np.max(np.abs(got - ref)) < 1e-12, rel_fro(got, ref)
 
 
+SHAPE_CASES = [('non-decreasing',), ('non-increasing',), ('unimodality', True), ('unimodality', False), ('GL smoothness', 0.7)]
+
+
+@pytest.mark.parametrize('c', SHAPE_CASES, ids=[c[0] + str(c[1:]) for c in SHAPE_CASES])
+@pytest.mark.parametrize('kind', ['long', 'verylong', 'staircase', 'ties', 'constant', 'negative', 'sorted', 'spike'])
+def test_shape_constraints_hard_inputs(eng, c, kind):
+    """The workgroup-parallel isotonic / unimodal projections and the cyclic-reduction GL solve (csrc/iso.hip) on the
+    inputs that are hard for them: columns beyond the LDS-resident sizes (2500 rows: global scratch for the isotonic
+    kernels; 5000 rows: sequential GL fallback), one outlier in front of sorted data (a pool that swallows the column
+    one entry at a time in sequential PAVA), exact ties, constant and all-negative columns."""
+    rng = np.random.default_rng(abs(hash(kind)) % 1000)
+    if kind == 'long':
+        X = rng.standard_normal((5000 if c[0] == 'GL smoothness' else 2500, 2))
+    elif kind == 'verylong':                            # beyond the LDS-resident prefix sums of iso_prev_k
+        X = rng.standard_normal((6500, 1))
+    elif kind == 'staircase':
+        X = np.sort(rng.standard_normal((1500, 3)), axis=0)
+        X[0, :] = 50.0
+        X[-1, 1] = -50.0
+    elif kind == 'ties':
+        X = rng.integers(-2, 3, size=(700, 4)).astype(float)
+    elif kind == 'constant':
+        X = np.full((300, 3), -0.75)
+        X[:, 1] = 2.0
+    elif kind == 'negative':
+        X = -np.abs(rng.standard_normal((400, 3))) - 0.1
+    elif kind == 'sorted':
+        X = np.sort(rng.standard_normal((1000, 2)), axis=0)
+        X[:, 1] = X[::-1, 1]
+    else:
+        X = 0.01 * rng.standard_normal((1200, 3))
+        X[600, :] = 5.0
+        X[100, 1] = 4.0
+    ops, _ = OP.constraints_to_prox([1], [c], [X.shape[0]])
+    ref = ops[0](X, 1.3)
+    got = eng.prox(c, X, 1.3)
+    assert rel_fro(got, ref) < 1e-10 or np.max(np.abs(got - ref)) < 1e-12, rel_fro(got, ref)
+
+
 def test_sphere_zero_column(eng):
     X = -np.abs(np.random.default_rng(0).standard_normal((9, 3)))
     assert np.array_equal(eng.prox(('non-negative l2-sphere', 1), X, 1.0), OP.prox_normalized_nonneg(X))
