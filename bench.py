@@ -74,6 +74,7 @@ def cpu_baseline(J, K, R, rows, full_rows):
     scale = full_rows / rows
     return {
         'value': 1.0 / (dt * scale), 'unit': 'iters/s', 'cores': int(threads), 'kind': 'port',
+        'extrapolated': True, 'slab_rows': int(rows), 'scale_to_full': float(scale),
         'sample': 'oracle (numpy/OpenBLAS CPU restatement, not MATLAB): 1 outer iteration (+ initial objective) on a '
                   '%dx%dx%d fp64 mode-1 slab took %.2f s; scaled x%.2f to %d rows' % (rows, J, K, dt, scale, full_rows),
     }
@@ -89,6 +90,8 @@ def parse_args(argv=None):
     ap.add_argument('--prec', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rows', type=int, default=64)
+    ap.add_argument('--no-drift', action='store_true',
+                    help='skip the fp64 repeat of the same iterations (N = 1, fp32 runs only) that measures the factor drift')
     return ap.parse_args(argv)
 
 
@@ -184,6 +187,8 @@ def main():
     t_gen = time.perf_counter()
     pkg.build_model(eng, Z, args.prec)                 # generates the tensor in HBM
     G = pkg.init_coupled_AOADMM_CMTF(Z, io, rng=rng, engine=eng)
+    import copy
+    G0 = copy.deepcopy(G)
     pkg.upload_state(eng, Z, G)
     eng.synchronize()
     t_gen = time.perf_counter() - t_gen
@@ -228,6 +233,33 @@ def main():
         mttkrp_ms = float(tt.item())
     capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 0, 1, None, None, None, None))
 
+    # fp32-tensor mode against the fp64 parity mode on the SAME synthetic tensor (same seed, generated in HBM), same init,
+    # same iterations: relative Frobenius gap of the factors.  Outside the timed region; the engines run one after the
+    # other (96 GB, then 192 GB of HBM at 2000^3).
+    drift = None
+    if world == 1 and args.prec == 'f32' and not args.no_drift:
+        try:
+            fac32 = pkg.download_state(eng, Z, G0)['fac']
+            eng.close()
+            eng = pkg.Engine(local_rank)
+            Z64 = build_Z(I, J, K, R, seed=0, noise=0.05)
+            Z64['_ranks'] = [R, R, R]
+            pkg.build_model(eng, Z64, 'f64')
+            pkg.upload_state(eng, Z64, copy.deepcopy(G0))
+            if args.warmup > 0:
+                pkg.run_solver(eng, opts(args.warmup), 3)
+            eng.synchronize()
+            t1 = time.perf_counter()
+            pkg.run_solver(eng, opts(args.steps), 3)
+            eng.synchronize()
+            dt64 = time.perf_counter() - t1
+            fac64 = pkg.download_state(eng, Z64, G0)['fac']
+            drift = {'factor_rel_fro_f32_vs_f64': [float(np.linalg.norm(a - b) / np.linalg.norm(b)) for a, b in zip(fac32, fac64)],
+                     'outer_iterations': args.warmup + args.steps, 'f64_ms_per_step': dt64 / args.steps * 1e3,
+                     'note': 'same synthetic tensor (seed 0) stored fp32 vs fp64, same init, same iteration counts'}
+        except Exception as e:   # a report, never a reason to lose the headline number
+            drift = {'error': repr(e)}
+
     if rank == 0:
         sx = 4.0 if args.prec == 'f32' else 8.0
         launches = max(int(nl.value), 1)
@@ -238,8 +270,11 @@ def main():
         # HBM bytes per launch from the PMC pass committed under profiles/ (separate rocprofv3 --pmc runs,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for this exact workload
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_contract16_f32.json')
-        if world == 1 and args.size == 2000 and R == 20 and args.prec == 'f32' and os.path.exists(pmc):
+        import glob
+        kname = 'contract16_f32' if args.prec == 'f32' else 'contract_f64'
+        cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_%s.json' % kname)))   # newest round last
+        pmc = cands[-1] if cands else ''
+        if world == 1 and args.size == 2000 and R == 20 and pmc:
             try:
                 traffic = float(json.load(open(pmc))['hbm_traffic_bytes_per_launch'])
             except Exception:
@@ -248,6 +283,8 @@ def main():
             'metric': 'AO-ADMM outer iters/sec (+ mode-1 MTTKRP GFLOP/s), %d^3 rank-%d CP' % (args.size, R),
             'value': args.steps / dt, 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            # everything that is not a tensor pass: T reductions, system builds, ADMM inner loops, Gram matrices
+            'replicated_tail_ms': dt / args.steps * 1e3 - (launches + int(nl1.value)) / args.steps * avg_ms,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': args.prec, 'data': 'synthetic',
             'config': {'workload': 'cfg5: %dx%dx%d R=%d CP, mode1 TV(0.001), modes2-3 nonneg, %s tensor + fp64 solve, '
                                    'MaxInnerIters=5, tol=0' % (I, J, K, R, args.prec),
@@ -260,6 +297,7 @@ def main():
             'mttkrp_mode1_ms': mttkrp_ms,
             'mttkrp_mfma_frac_f32_peak': flops_mttkrp / (mttkrp_ms * 1e-3) / 1e12 / (F32_MFMA_PEAK_TF * world),
             'f_tensors_last': out['f_tensors'],
+            'fp32_drift': drift,
             'collectives': {'backend': 'rccl' if world > 1 else 'none', 'ranks': comm['comm_ranks'],
                             'rccl_version': comm['rccl_version'], 'librccl': comm['librccl']},
             'datagen_s': t_gen,
@@ -270,7 +308,7 @@ def main():
                          'algorithmic_bytes_per_launch': bytes_per_launch,
                          'note': 'per rank; algorithmic bytes = local tensor block read once (s_X per entry) + T written once '
                                  '(s_X*R per unfolding row); traffic = FETCH_SIZE x2 + WRITE_SIZE of a separate rocprofv3 --pmc '
-                                 'run (profiles/r01_pmc_contract16_f32.json)'},
+                                 'run (%s)' % (os.path.relpath(pmc, ROOT) if pmc else 'none for this workload')},
             'second_kernel': {'kernel': 'contract_lead16_f32 (leading-mode contraction, LDS-transposed): only used when the '
                                         'mode-permuted second copy of the tensor is switched off or does not fit',
                               'launches': int(nl1.value),

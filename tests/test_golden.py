@@ -78,3 +78,17 @@ def test_gpu_reproduces_golden_run(data, expected):
     with pkg.Engine(0) as eng:
         _, Fac, _, out = pkg.cmtf_AOADMM(Z, alg_options=script11_options(40), init=copy.deepcopy(G), engine=eng)
     check_against_expected(Fac, out, expected, 1e-8)
+
+
+@pytest.mark.gpu
+def test_gpu_script11_known_answer_recovers_ground_truth(data, expected):
+    """The one expected value that comes from the reference itself (example_script11_tPARAFAC2.m:160-164: FMS of the
+    recovered A and C against gnd_factors.mat), checked on the HIP path directly -- not through the oracle's output:
+    the script's model and options, 300 outer iterations on the device, same bar as for the oracle."""
+    pkg = importlib.import_module('matlab-code_amd')
+    Z = script11_model(data['dataset'])
+    G = unpack_G(expected, 'init_')
+    with pkg.Engine(0) as eng:
+        _, Fac, _, out = pkg.cmtf_AOADMM(Z, alg_options=script11_options(300, tol0=False), init=copy.deepcopy(G), engine=eng)
+    assert fms(Fac['fac'][0], data['A']) > 0.98
+    assert fms(Fac['fac'][2], data['C']) > 0.98

@@ -35,6 +35,59 @@ def test_config2_500cube_rank10_fp64(pkg, eng):
     assert np.allclose(og['func_val_conv'], oo['func_val_conv'], rtol=1e-8)
 
 
+def test_config2_500cube_fp32_tensor_mode_vs_oracle(pkg, eng):
+    """The throughput mode (fp32 tensor, fp64 everywhere else) at config 2's size against the fp64 oracle, TV + non-negativity
+    as in the headline workload.  Stated tolerance: 2e-5 relative Frobenius on every factor and 1e-5 on the objective after
+    5 outer iterations -- the fp32 rounding of the 1.25e8 tensor entries (relative 6e-8 each) and the fp32 accumulation of
+    the contractions (500 terms) enter every MTTKRP; they do not grow over the iterations at this size."""
+    rng = np.random.default_rng(23)
+    n, R = 500, 10
+    A = [rng.random((n, R)) for _ in range(3)]
+    X = np.einsum('ir,jr,kr->ijk', *A, optimize=True)
+    X += 0.05 * np.linalg.norm(X) / np.sqrt(X.size) * rng.standard_normal(X.shape)
+    X /= np.linalg.norm(X)
+    X = np.asfortranarray(X)
+    Z = dict(loss_function=['Frobenius'], model=['CP'], modes=[[1, 2, 3]], size=[n, n, n],
+             coupling=dict(lin_coupled_modes=[0, 0, 0], coupling_type=[], coupl_trafo_matrices=[None] * 3),
+             constrained_modes=[1, 1, 1], constraints=[('TV regularization', 0.001), ('non-negativity',), ('non-negativity',)],
+             weights=[1.0], object=[X])
+    io = dict(lambdas_init=[[1] * R], nvecs=0, distr=[lambda a, b: rng.random((a, b))] * 3, normalize=1)
+    G = OA.init_coupled_AOADMM_CMTF(Z, io, rng=rng)
+    opt = options(MaxOuterIters=5)
+    _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
+    _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=eng, precision='f32')
+    drift = [rel_fro(b, a) for a, b in zip(Fo['fac'], Fg['fac'])]
+    print('fp32-tensor mode vs fp64 oracle at 500^3 after 5 iterations:', drift,
+          float(np.max(np.abs(og['func_val_conv'] / oo['func_val_conv'] - 1))))
+    assert max(drift) < 2e-5, drift
+    assert np.allclose(og['func_val_conv'], oo['func_val_conv'], rtol=1e-5)
+
+
+def test_config5_2000cube_fp32_vs_fp64_factor_drift(pkg):
+    """config 5 itself: the same synthetic 2000^3 tensor (generated in HBM from the same seed) solved in the fp32-tensor
+    mode and in the fp64 parity mode, 10 outer iterations each from the same init; the factors of the two runs are
+    compared.  Stated tolerance 1e-6 relative Frobenius (measured 5e-8 / 2e-8 / 5e-9 for the three modes, DESIGN.md
+    section 2); the two runs need 96 GB and 192 GB of HBM one after the other."""
+    import bench
+    n, R = 2000, 20
+    facs = {}
+    for prec in ('f32', 'f64'):
+        rng = np.random.default_rng(1)
+        Z = bench.build_Z(n, n, n, R, seed=0, noise=0.05)
+        Z['_ranks'] = [R] * 3
+        io = dict(lambdas_init=[[1] * R], nvecs=0, distr=[lambda a, b: rng.random((a, b))] * 3, normalize=1)
+        with pkg.Engine(0) as e:
+            pkg.build_model(e, Z, prec)
+            G = pkg.init_coupled_AOADMM_CMTF(Z, io, rng=rng, engine=e)
+            pkg.upload_state(e, Z, G)
+            pkg.run_solver(e, dict(MaxOuterIters=10, MaxInnerIters=5, AbsFuncTol=0.0, OuterRelTol=0.0, innerRelPrTol_coupl=0.0,
+                                   innerRelPrTol_constr=0.0, innerRelDualTol_coupl=0.0, innerRelDualTol_constr=0.0, bsum=0), 3)
+            facs[prec] = pkg.download_state(e, Z, G)['fac']
+    drift = [rel_fro(a, b) for a, b in zip(facs['f32'], facs['f64'])]
+    print('fp32-vs-fp64 factor drift at 2000^3 after 10 iterations:', drift)
+    assert max(drift) < 1e-6, drift
+
+
 def test_config4_parafac2_256_slabs(pkg, eng):
     """config 4: irregular PARAFAC2, I = 40, R = 3, K = 256 slabs with J_k cycled over 61..120, C non-negative."""
     from helpers import script4_model
