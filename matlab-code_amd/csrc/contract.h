@@ -34,6 +34,7 @@ struct ContractPlan {
   bool lead = false;   // true: the contracted mode is the contiguous one (X[c + ld*m]), LDS-transposed kernel
   bool on_xp = false;  // the pass runs on the mode-permuted second copy of the tensor (solver.h CpBlock::Xp)
   bool on_xq = false;  // ... on the third copy Xq(k,i,j) (mode 2 trailing)
+  bool on_xc = false;  // ... on the row-blocked copy of X itself (mode 3 trailing)
   int64_t trows() const { return nbatch * M; }
   size_t t_bytes() const { return (size_t)nchunk * trows() * R * (tprec == AOADMM_PREC_F32 ? 4 : 8); }
   size_t frag_bytes(int prec) const;

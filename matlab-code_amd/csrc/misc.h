@@ -37,9 +37,12 @@ size_t synth_ws_bytes();
 void reg_value(double* slot, int type, double p0, const double* X, int64_t rows, int R, double* ws,
                hipStream_t s);
 
-// Xp(j,k,i) = X(i,j,k), leading dimensions Ip (X) and Jp (Xp); padding rows of Xp are written as zeros
-void permute_231(const void* X, void* Xp, int prec, int64_t I, int64_t Ip, int64_t J, int64_t Jp, int64_t K,
-                 hipStream_t s);
+// Pass-specific resident copy of a 3-way tensor in the row-blocked layout of misc.hip (which = 0, 1, 2: the copy for
+// the pass that contracts mode 3, 1, 2).  D holds round_up(M, kRowBlockElems) * C elements.  false: a mode is too long
+// for one launch (the caller keeps the natural layout).
+constexpr int64_t kRowBlockElems = 512;
+bool block_layout_copy(const void* X, void* D, int which, int prec, int64_t I, int64_t Ip, int64_t J, int64_t K,
+                       int64_t Tp, hipStream_t s);
 // Y = X_(n) X_(n)' of a resident dense block (cmtf_nvecs.m:56): row a of the unfolding at X + a*sa, reduction
 // over t1 < n1 (stride s1) x t2 < n2 (stride s2); Y is n x n column-major fp64.
 struct UnfoldGramArgs {

@@ -245,36 +245,86 @@ void reg_value(double* slot, int type, double p0, const double* X, int64_t rows,
 }
 
 // ---------------------------------------------------------------------------
-// Xp(j, k, i) = X(i, j, k): second resident copy of a 3-way tensor with the first mode moved to the back, so that
-// the contraction over mode 1 streams like the trailing-mode contractions instead of needing the LDS-transposed
-// kernel.  32 x 32 tiles through LDS per k; Xp's leading dimension J is padded to Jp (padding written as zeros).
+// Resident copies of a 3-way tensor, one per tensor pass, each in the layout its pass streams best (solver.h CpBlock).
+// A pass contracts column index c of an "unfolding" whose row index m is the contiguous one.  Rows are cut into blocks
+// of kRowBlockElems; a block stores its columns one after the other,
+//     element (m, c)  ->  (m / MB) * MB * C  +  c * MB  +  m % MB ,
+// so the workgroups that own a block read ONE contiguous range of MB*C elements from front to back instead of one
+// 2 KB piece per column, 4*ld bytes apart (2000^3 fp32: 4.80-4.92 ms against 4.96-5.09 ms per pass on the same
+// buffers, tools/micro/pass_placement.hip).  Rows beyond the data (up to the next multiple of MB) are zeros.
+//   which = 0  (contracts mode 3):  m = i + Ip*j, c = k     -- a re-blocked copy, no transposition
+//   which = 1  (contracts mode 1):  m = j + Jp*k, c = i     -- 32 x 32 tiles over (i, j) through LDS per k
+//   which = 2  (contracts mode 2):  m = k + Kp*i, c = j     -- 32 x 32 tiles over (i, k) through LDS per j
+// Jp / Kp: J / K padded to a multiple of 4 (fp32) or 2 (fp64); the padding rows are written as zeros.
 template <typename T>
-__global__ __launch_bounds__(256) void permute_231_k(const T* __restrict__ X, T* __restrict__ Xp, int64_t I,
-                                                    int64_t Ip, int64_t J, int64_t Jp, int64_t K) {
-  __shared__ T tile[32][33];
-  const int64_t k = blockIdx.z;
-  const int64_t i0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
-  const T* Xk = X + Ip * J * k;
+__global__ __launch_bounds__(256) void block_copy_k(const T* __restrict__ X, T* __restrict__ D, int64_t M, int64_t Mpad,
+                                                   int64_t K, int64_t MB) {
+  const int64_t k = blockIdx.y;
+  constexpr int V = 16 / sizeof(T);
+  typedef T VT __attribute__((ext_vector_type(V)));
+  for (int64_t m = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V; m < Mpad; m += (int64_t)gridDim.x * 256 * V) {
+    VT v;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int64_t i = i0 + tx, j = j0 + ty + 8 * q;
-    tile[ty + 8 * q][tx] = (i < I && j < J) ? Xk[i + Ip * j] : (T)0;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int64_t j = j0 + tx, i = i0 + ty + 8 * q;
-    if (j < Jp && i < I) Xp[j + Jp * (k + K * i)] = tile[tx][ty + 8 * q];   // j >= J: zeros from the load guard
+    for (int e = 0; e < V; ++e) v[e] = (T)0;
+    if (m < M) v = *reinterpret_cast<const VT*>(X + M * k + m);       // M is a multiple of V (padded first dimension)
+    *reinterpret_cast<VT*>(D + (m / MB) * MB * K + k * MB + m % MB) = v;
   }
 }
-void permute_231(const void* X, void* Xp, int prec, int64_t I, int64_t Ip, int64_t J, int64_t Jp, int64_t K,
-                 hipStream_t s) {
-  AO_REQUIRE(K <= 65535 && cdiv(Jp, 32) <= 65535, "permute_231: mode too long for one launch");
-  const dim3 grid((unsigned)cdiv(I, 32), (unsigned)cdiv(Jp, 32), (unsigned)K);
-  if (prec == AOADMM_PREC_F32) permute_231_k<float><<<grid, 256, 0, s>>>((const float*)X, (float*)Xp, I, Ip, J, Jp, K);
-  else permute_231_k<double><<<grid, 256, 0, s>>>((const double*)X, (double*)Xp, I, Ip, J, Jp, K);
+template <typename T, int WHICH>
+__global__ __launch_bounds__(256) void block_permute_k(const T* __restrict__ X, T* __restrict__ D, int64_t I, int64_t Ip,
+                                                      int64_t J, int64_t K, int64_t Tp, int64_t MB) {
+  __shared__ T tile[32][33];
+  // WHICH 1: t = j (extent J, padded Tp), u = k;  WHICH 2: t = k (extent K, padded Tp), u = j
+  const int64_t u = blockIdx.z;
+  const int64_t i0 = (int64_t)blockIdx.x * 32, t0 = (int64_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+  const int64_t nT = WHICH == 1 ? J : K;
+  const int64_t st = WHICH == 1 ? Ip : Ip * J, su = WHICH == 1 ? Ip * J : Ip;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t i = i0 + tx, t = t0 + ty + 8 * q;
+    tile[ty + 8 * q][tx] = (i < I && t < nT) ? X[i + st * t + su * u] : (T)0;
+  }
+  __syncthreads();
+  const int64_t C = WHICH == 1 ? I : J;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t t = t0 + tx, i = i0 + ty + 8 * q;
+    if (t < Tp && i < I) {                              // t >= nT: zeros from the load guard
+      const int64_t m = WHICH == 1 ? t + Tp * u : t + Tp * i;
+      const int64_t c = WHICH == 1 ? i : u;
+      D[(m / MB) * MB * C + c * MB + m % MB] = tile[tx][ty + 8 * q];
+    }
+  }
+}
+bool block_layout_copy(const void* X, void* D, int which, int prec, int64_t I, int64_t Ip, int64_t J, int64_t K,
+                       int64_t Tp, hipStream_t s) {
+  const int64_t MB = kRowBlockElems;
+  const size_t es = prec == AOADMM_PREC_F32 ? 4 : 8;
+  if (which == 0) {
+    if (K > 65535) return false;
+    const int64_t M = Ip * J, Mpad = round_up(M, MB);
+    const int V = (int)(16 / es);
+    int64_t gx = cdiv(Mpad, (int64_t)256 * V);
+    if (gx > 65535) gx = 65535;
+    const dim3 grid((unsigned)gx, (unsigned)K);
+    if (prec == AOADMM_PREC_F32) block_copy_k<float><<<grid, 256, 0, s>>>((const float*)X, (float*)D, M, Mpad, K, MB);
+    else block_copy_k<double><<<grid, 256, 0, s>>>((const double*)X, (double*)D, M, Mpad, K, MB);
+    AO_KERNEL_CHECK();
+    return true;
+  }
+  const int64_t nU = which == 1 ? K : J, C = which == 1 ? I : J;
+  const int64_t M = which == 1 ? Tp * K : Tp * I, Mpad = round_up(M, MB);
+  if (nU > 65535 || cdiv(Tp, 32) > 65535) return false;
+  if (Mpad > M)                                        // rows of the last block beyond the data
+    AO_HIP(hipMemsetAsync((char*)D + (size_t)(Mpad / MB - 1) * MB * C * es, 0, (size_t)MB * C * es, s));
+  const dim3 grid((unsigned)cdiv(I, 32), (unsigned)cdiv(Tp, 32), (unsigned)nU);
+#define AO_BP(TT, W) block_permute_k<TT, W><<<grid, 256, 0, s>>>((const TT*)X, (TT*)D, I, Ip, J, K, Tp, MB)
+  if (prec == AOADMM_PREC_F32) { if (which == 1) AO_BP(float, 1); else AO_BP(float, 2); }
+  else { if (which == 1) AO_BP(double, 1); else AO_BP(double, 2); }
+#undef AO_BP
   AO_KERNEL_CHECK();
+  return true;
 }
 
 // ---------------------------------------------------------------------------

@@ -41,6 +41,10 @@ struct CpBlock {
   DevBuf Xq;
   int64_t Kp = 0;
   bool has_xq = false, xq_refused = false;
+  // and a copy for the pass that contracts mode 3: same row order as X, but row-blocked like the other two
+  // (misc.hip block_layout_copy); all three copies are stored in that layout
+  DevBuf Xc;
+  bool has_xc = false, xc_refused = false;
   int nd = 0;
   int64_t dims[8] = {0};   // local sizes (dims[0] = local rows when sharded)
   int64_t full0 = 0;       // global size of the first mode
@@ -210,6 +214,7 @@ class Engine {
                           int nseq);
   bool ensure_permuted_copy(CpBlock& b);
   bool ensure_permuted_copy2(CpBlock& b);
+  bool ensure_blocked_copy(CpBlock& b);
   void drop_permuted_copies(CpBlock& b);
   bool prefetch_next_contraction(const aoadmm_options& opt);   // true: a tensor pass was enqueued
   // `collective` = false: the block holds the whole tensor and the result is complete on this engine (op-level

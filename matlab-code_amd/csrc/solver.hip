@@ -504,8 +504,8 @@ void Engine::block_upload(CpBlock& b, int nd, const int64_t* dims, const double*
   }
   b.has_data = true;
   b.cached_mode = -1;
-  b.has_xp = false; b.xp_refused = false; b.has_xq = false; b.xq_refused = false;
-  if (nd == 3) (void)ensure_permuted_copy2(b);       // one-off set-up cost belongs to the upload, not to the first solve
+  b.has_xp = false; b.xp_refused = false; b.has_xq = false; b.xq_refused = false; b.has_xc = false; b.xc_refused = false;
+  if (nd == 3) { (void)ensure_permuted_copy2(b); (void)ensure_blocked_copy(b); }   // one-off set-up cost belongs to the upload
 }
 
 void Engine::tensor_upload(int p, const double* data, int prec, int64_t row0, int64_t local_rows) {
@@ -618,8 +618,9 @@ void Engine::tensor_synth(int p, int rank, uint64_t seed, double noise, int prec
   AO_HIP(hipStreamSynchronize(stream_));
   b.has_data = true;
   b.cached_mode = -1;
-  b.has_xp = false; b.xp_refused = false; b.has_xq = false; b.xq_refused = false;
+  b.has_xp = false; b.xp_refused = false; b.has_xq = false; b.xq_refused = false; b.has_xc = false; b.xc_refused = false;
   (void)ensure_permuted_copy2(b);                    // set-up cost of the data, like the generation itself
+  (void)ensure_blocked_copy(b);
   AO_HIP(hipStreamSynchronize(stream_));
   t.normsq_valid = false;
 }
@@ -903,45 +904,63 @@ static int next_update_distance(int pos, int c, const int* seq, int n) {
 // position `pos` (a cached one is reused while its factor is unchanged).
 // Second resident copy with the first mode last (see CpBlock::Xp).  Built lazily; refused when the mask of an EM
 // problem would have to be kept in sync, when the caller opted out, or when HBM cannot hold it.
+static size_t blocked_bytes(int64_t M, int64_t C, size_t es) { return (size_t)round_up(M, kRowBlockElems) * C * es; }
+static bool room_for(size_t bytes) {
+  size_t free_b = 0, total_b = 0;
+  return hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= bytes + (size_t)(4ull << 30);
+}
+
 bool Engine::ensure_permuted_copy(CpBlock& b) {
   if (b.has_xp) return true;
   if (b.xp_refused || !allow_xp_ || b.has_mask || b.nd != 3) return false;
   const int64_t I = b.dims[0], J = b.dims[1], K = b.dims[2];
   const int64_t Jp = round_up(J, b.X.prec == AOADMM_PREC_F32 ? 4 : 2);
-  const size_t bytes = (size_t)Jp * K * I * b.X.elem_size();
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (size_t)(4ull << 30) || K > 65535) {
-    b.xp_refused = true;
-    return false;
-  }
+  const size_t bytes = blocked_bytes(Jp * K, I, b.X.elem_size());
+  if (!room_for(bytes)) { b.xp_refused = true; return false; }
   b.Xp.alloc(bytes);
   b.Jp = Jp;
-  permute_231(b.X.data.p, b.Xp.p, b.X.prec, I, b.X.pad0, J, Jp, K, stream_);
+  if (!block_layout_copy(b.X.data.p, b.Xp.p, 1, b.X.prec, I, b.X.pad0, J, K, Jp, stream_)) {
+    b.Xp.release(); b.xp_refused = true; return false;
+  }
   b.has_xp = true;
   return true;
 }
 
-// Xq(k,i,j) = X(i,j,k), built from Xp(j,k,i) by the same 231 permutation
+// Xq: rows (k, i), columns j -- built from X directly
 bool Engine::ensure_permuted_copy2(CpBlock& b) {
   if (b.has_xq) return true;
   if (b.xq_refused || !ensure_permuted_copy(b)) return false;
   const int64_t I = b.dims[0], J = b.dims[1], K = b.dims[2];
   const int64_t Kp = round_up(K, b.X.prec == AOADMM_PREC_F32 ? 4 : 2);
-  const size_t bytes = (size_t)Kp * I * J * b.X.elem_size();
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (size_t)(4ull << 30) || I > 65535) {
-    b.xq_refused = true;
-    return false;
-  }
+  const size_t bytes = blocked_bytes(Kp * I, J, b.X.elem_size());
+  if (!room_for(bytes)) { b.xq_refused = true; return false; }
   b.Xq.alloc(bytes);
   b.Kp = Kp;
-  permute_231(b.Xp.p, b.Xq.p, b.X.prec, J, b.Jp, K, Kp, I, stream_);
+  if (!block_layout_copy(b.X.data.p, b.Xq.p, 2, b.X.prec, I, b.X.pad0, J, K, Kp, stream_)) {
+    b.Xq.release(); b.xq_refused = true; return false;
+  }
   b.has_xq = true;
+  return true;
+}
+
+// Xc: the rows of X itself, row-blocked (the pass that contracts mode 3)
+bool Engine::ensure_blocked_copy(CpBlock& b) {
+  if (b.has_xc) return true;
+  if (b.xc_refused || !allow_xp_ || b.has_mask || b.nd != 3) return false;
+  const int64_t I = b.dims[0], J = b.dims[1], K = b.dims[2];
+  const size_t bytes = blocked_bytes(b.X.pad0 * J, K, b.X.elem_size());
+  if (!room_for(bytes)) { b.xc_refused = true; return false; }
+  b.Xc.alloc(bytes);
+  if (!block_layout_copy(b.X.data.p, b.Xc.p, 0, b.X.prec, I, b.X.pad0, J, K, 0, stream_)) {
+    b.Xc.release(); b.xc_refused = true; return false;
+  }
+  b.has_xc = true;
   return true;
 }
 void Engine::drop_permuted_copies(CpBlock& b) {
   if (b.has_xp) { b.Xp.release(); b.has_xp = false; b.cached_mode = -1; }
   if (b.has_xq) { b.Xq.release(); b.has_xq = false; b.cached_mode = -1; }
+  if (b.has_xc) { b.Xc.release(); b.has_xc = false; b.cached_mode = -1; }
 }
 
 void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int R, bool use_cache,
@@ -966,11 +985,22 @@ void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int 
   }
   ContractPlan pl;
   const double* Fc = facs[c].p;
-  if (c == 2) pl = make_plan(1, 0, Ip * J, Ip * J, K, R, prec);
-  else if (c == 1) {
+  // a pass on a row-blocked copy: one "batch" per row block, each a contiguous MB x C matrix
+  auto blocked_plan = [&](int64_t M, int64_t C) {
+    const int64_t MB = kRowBlockElems;
+    return make_plan(round_up(M, MB) / MB, MB * C, MB, MB, C, R, prec);
+  };
+  if (c == 2) {
+    if (use_cache && ensure_blocked_copy(b)) {
+      pl = blocked_plan(Ip * J, K);
+      pl.on_xc = true;
+    } else {
+      pl = make_plan(1, 0, Ip * J, Ip * J, K, R, prec);
+    }
+  } else if (c == 1) {
     if (use_cache && ensure_permuted_copy2(b)) {
-      // Xq(k,i,j): mode 2 is the trailing index with stride Kp*I -> one streaming pass instead of K batches
-      pl = make_plan(1, 0, b.Kp * I, b.Kp * I, J, R, prec);
+      // Xq: rows (k, i), columns j -> one streaming pass instead of K batches of an I x J matrix
+      pl = blocked_plan(b.Kp * I, J);
       pl.on_xq = true;
     } else {
       pl = make_plan(K, Ip * J, Ip, Ip, J, R, prec);
@@ -979,15 +1009,16 @@ void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int 
     Fc = facs[0].p + (sharded() ? b.row0 : 0);
     static const bool force_ldskernel = getenv("AOADMM_LEAD_KERNEL") != nullptr;   // development switch
     if (!force_ldskernel && ensure_permuted_copy(b)) {
-      // Xp(j,k,i): mode 1 is the trailing index with stride Jp*K -> the register-streaming contraction
-      pl = make_plan(1, 0, b.Jp * K, b.Jp * K, I, R, prec);
+      // Xp: rows (j, k), columns i -> the register-streaming contraction
+      pl = blocked_plan(b.Jp * K, I);
       pl.on_xp = true;
     } else {
       pl = make_lead_plan(J * K, Ip, I, R);
     }
   }
   b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
-  timed_contract(pl.on_xp ? b.Xp.p : (pl.on_xq ? b.Xq.p : b.X.data.p), prec, pl, Fc, facs[c].ld, b.frag.p, b.T.p);
+  timed_contract(pl.on_xp ? b.Xp.p : (pl.on_xq ? b.Xq.p : (pl.on_xc ? b.Xc.p : b.X.data.p)), prec, pl, Fc, facs[c].ld, b.frag.p,
+                 b.T.p);
   b.cached_mode = c; b.cached_version = facs[c].version; b.plan = pl;
 }
 
@@ -2335,7 +2366,9 @@ void Engine::resident_mttkrp(int p, int pos, double* out_host, float* ms) {
   hipEvent_t e0, e1;
   AO_HIP(hipEventCreate(&e0)); AO_HIP(hipEventCreate(&e1));
   AO_HIP(hipEventRecord(e0, stream_));
-  block_mttkrp(t.blk, pos, facs, mi.R, 1.0, mi.A.d(), mi.rows, false, nullptr, 0);
+  t.blk.cached_mode = -1;                              // a full MTTKRP: tensor pass + reduction, on the pass's resident copy
+  block_mttkrp(t.blk, pos, facs, mi.R, 1.0, mi.A.d(), mi.rows, true, nullptr, 0);
+  t.blk.cached_mode = -1;                              // the solver's own factors may differ from what this pass used
   AO_HIP(hipEventRecord(e1, stream_));
   AO_HIP(hipEventSynchronize(e1));
   float tms = 0.f;
