@@ -7,6 +7,7 @@
 #include "device_utils.h"
 #include "hosteig.h"
 #include "loopctl.h"
+#include "prox_dev.h"
 
 namespace aoadmm {
 
@@ -19,45 +20,6 @@ namespace aoadmm {
 bool prox_is_fusable(int t) {
   return t == AOADMM_C_NONNEG || t == AOADMM_C_BOX || t == AOADMM_C_L1_REG || t == AOADMM_C_L0_REG ||
          t == AOADMM_C_RIDGE || t == AOADMM_C_SIMPLEX_ROW;
-}
-
-__device__ __forceinline__ double prox_elem(int type, double v, double p0, double p1, double rho) {
-  switch (type) {
-    case AOADMM_C_NONNEG: return fmax(v, 0.0);                          // project_box(x,0,inf)  (:14)
-    case AOADMM_C_BOX: return fmin(fmax(v, p0), p1);                    // (:18)
-    case AOADMM_C_L1_REG: {                                             // prox_abs(x,eta/rho) (:48)
-      const double g = p0 / rho;
-      const double m = fabs(v) - g;
-      return m > 0.0 ? copysign(m, v) : 0.0;
-    }
-    case AOADMM_C_L0_REG: {                                             // prox_zero (:52)
-      const double g = p0 / rho;
-      return v * v > 2.0 * g ? v : 0.0;
-    }
-    case AOADMM_C_RIDGE: return 1.0 / (2.0 * (p0 / rho) + 1.0) * v;     // (:60)
-    default: return v;
-  }
-}
-
-// exact projection of v[0..R) onto {x >= 0, sum x = eta}: fixed point of
-// tau <- (sum_{v_i > tau} v_i - eta) / #{v_i > tau}  (nested active sets, finite termination)
-template <int RMAX>
-__device__ __forceinline__ void simplex_regs(double (&v)[RMAX], int R, double eta) {
-  double tau = -INFINITY;
-  int cnt_prev = -1;
-  for (int it = 0; it <= RMAX; ++it) {
-    double sum = 0.0;
-    int cnt = 0;
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r)
-      if (r < R && v[r] > tau) { sum += v[r]; ++cnt; }
-    if (cnt == cnt_prev || cnt == 0) break;
-    cnt_prev = cnt;
-    tau = (sum - eta) / cnt;
-  }
-#pragma unroll
-  for (int r = 0; r < RMAX; ++r)
-    if (r < R) v[r] = fmax(v[r] - tau, 0.0);
 }
 
 // ===========================================================================
@@ -104,28 +66,6 @@ struct FusedArgs {
   int it, max_inner, nparts_prev;
   double p0, p1, tol_pr, tol_du;
 };
-
-// branch-free form of the element-wise prox catalogue (same arithmetic per constraint as prox_elem):
-//   z = scale * clamp(hard(soft(v, g), thr0), lo, hi)
-struct ElemProx { double g, thr0, lo, hi, scale; };
-__device__ __forceinline__ ElemProx elem_prox_of(int type, double p0, double p1, double rho) {
-  ElemProx e{0.0, -1.0, -INFINITY, INFINITY, 1.0};
-  switch (type) {
-    case AOADMM_C_NONNEG: e.lo = 0.0; break;                              // project_box(x,0,inf)  (:14)
-    case AOADMM_C_BOX: e.lo = p0; e.hi = p1; break;                       // (:18)
-    case AOADMM_C_L1_REG: e.g = p0 / rho; break;                          // prox_abs(x,eta/rho) (:48)
-    case AOADMM_C_L0_REG: e.thr0 = 2.0 * (p0 / rho); break;               // prox_zero (:52)
-    case AOADMM_C_RIDGE: e.scale = 1.0 / (2.0 * (p0 / rho) + 1.0); break; // (:60)
-    default: break;
-  }
-  return e;
-}
-__device__ __forceinline__ double elem_prox(const ElemProx& e, double v) {
-  double s = v;
-  if (e.g != 0.0) { const double m = fabs(v) - e.g; s = m > 0.0 ? copysign(m, v) : 0.0; }
-  if (!(v * v > e.thr0)) s = 0.0;
-  return e.scale * fmin(fmax(s, e.lo), e.hi);
-}
 
 // One inner iteration of ADMM_constrained_only for 64 rows per 256-thread block: wave w owns output
 // columns [w*CPW, (w+1)*CPW) of those rows (lane = row), so the per-row solve fac = A_inner*inv(L*L')
@@ -1481,10 +1421,64 @@ __global__ void dual_sums_fin_k(double* slots, const double* ws, int nb, const A
   slots[threadIdx.x] = t;
 }
 
+// update_constraint (:1420-1429) with an element-/row-wise prox in ONE launch of one workgroup (thread = row):
+// Zold = Z, Z = prox(fac + mu, rho), mu += fac - Z and the four sums of eval_res_ADMM_constr.  The three-launch form
+// below (fac + mu, prox, dual + sums) is ~12 us of launches per call; the coupled and PARAFAC2 loops of the example
+// scripts call it 4-15 times per outer iteration.
+template <int RMAX>
+__global__ __launch_bounds__(256) void constraint_update_rows_k(ColArgs a, const double* fac, double* mu, double* Zold,
+                                                               double* slots, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  __shared__ double sh4[4];
+  const double rho = a.rho[0] * a.rho_mul;
+  const int R = a.R;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int64_t i = threadIdx.x; i < a.rows; i += 256) {
+    double f[RMAX], m[RMAX], zo[RMAX], z[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const bool ok = r < R;
+      f[r] = ok ? fac[i + a.rows * r] : 0.0;
+      m[r] = ok ? mu[i + a.rows * r] : 0.0;
+      zo[r] = ok ? a.Z[i + a.ldz * r] : 0.0;
+      z[r] = f[r] + m[r];
+    }
+    if (a.type == AOADMM_C_SIMPLEX_ROW) {
+      simplex_regs<RMAX>(z, R, a.p0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) z[r] = prox_elem(a.type, z[r], a.p0, a.p1, rho);
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (r < R) {
+        const double mn = m[r] + f[r] - z[r];
+        Zold[i + a.rows * r] = zo[r];
+        a.Z[i + a.ldz * r] = z[r];
+        mu[i + a.rows * r] = mn;
+        const double dz = z[r] - zo[r];
+        s0 += (f[r] - z[r]) * (f[r] - z[r]); s1 += f[r] * f[r]; s2 += mn * mn; s3 += dz * dz;
+      }
+  }
+  s0 = block256_sum(s0, sh4); s1 = block256_sum(s1, sh4); s2 = block256_sum(s2, sh4); s3 = block256_sum(s3, sh4);
+  if (threadIdx.x == 0) { slots[0] = s0; slots[1] = s1; slots[2] = s2; slots[3] = s3; }
+}
+
 void constraint_update(const ProxSpec& ps, const double* fac, double* Z, double* mu, double* Zold,
                        double* V, int64_t rows, int R, const double* rho_dev, double rho_mul,
                        double* prox_ws, double* slots, double* red_ws, const AdmmCtl* ctl,
                        hipStream_t s) {
+  if (prox_is_fusable(ps.type) && rows <= 8192 && R <= 32) {
+    ColArgs a;
+    a.V = nullptr; a.Z = Z; a.ldv = rows; a.ldz = rows; a.rows = rows; a.R = R; a.type = ps.type;
+    a.p0 = ps.p0; a.p1 = ps.p1; a.rho = rho_dev; a.rho_mul = rho_mul; a.ws = nullptr;
+    if (R <= 4) constraint_update_rows_k<4><<<1, 256, 0, s>>>(a, fac, mu, Zold, slots, ctl);
+    else if (R <= 8) constraint_update_rows_k<8><<<1, 256, 0, s>>>(a, fac, mu, Zold, slots, ctl);
+    else if (R <= 16) constraint_update_rows_k<16><<<1, 256, 0, s>>>(a, fac, mu, Zold, slots, ctl);
+    else constraint_update_rows_k<32><<<1, 256, 0, s>>>(a, fac, mu, Zold, slots, ctl);
+    AO_KERNEL_CHECK();
+    return;
+  }
   const int64_t n = rows * R;
   int64_t nb = cdiv(n, 256);
   if (nb > 1024) nb = 1024;

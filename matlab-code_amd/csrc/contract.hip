@@ -836,7 +836,7 @@ template <> struct TVec<double, 1> { typedef double type; };
 template <typename TT, int VEC>
 __device__ __forceinline__ void fma_vec(double (&acc)[VEC], const TT* __restrict__ tp, const double* __restrict__ fp) {
   typedef typename TVec<TT, VEC>::type V;
-  const V tv = *reinterpret_cast<const V*>(tp);
+  const V tv = __builtin_nontemporal_load(reinterpret_cast<const V*>(tp));
   if constexpr (VEC == 1) {
     acc[0] += (double)tv * fp[0];
   } else {
@@ -853,7 +853,7 @@ struct RVec {
   typename TVec<TT, VEC>::type t;
   double f[VEC];
   __device__ __forceinline__ void load(const TT* __restrict__ tp, const double* __restrict__ fp) {
-    t = *reinterpret_cast<const typename TVec<TT, VEC>::type*>(tp);
+    t = __builtin_nontemporal_load(reinterpret_cast<const typename TVec<TT, VEC>::type*>(tp));   // T is read once per pass
 #pragma unroll
     for (int v = 0; v < VEC; ++v) f[v] = fp[v];
   }
@@ -929,8 +929,8 @@ __global__ void reduce_inner2_k(const TT* __restrict__ T, int nchunk, int64_t tr
       RVec<TT, VEC> q0, q1, p0, p1;
       q0.load(Ta + e, FaT + e);
       q1.load(Ta + e + step, FaT + e + step);
-      p0.t = *reinterpret_cast<const typename TVec<TT, VEC>::type*>(Tc + e);
-      p1.t = *reinterpret_cast<const typename TVec<TT, VEC>::type*>(Tc + e + step);
+      p0.t = __builtin_nontemporal_load(reinterpret_cast<const typename TVec<TT, VEC>::type*>(Tc + e));
+      p1.t = __builtin_nontemporal_load(reinterpret_cast<const typename TVec<TT, VEC>::type*>(Tc + e + step));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) { p0.f[v] = q0.f[v]; p1.f[v] = q1.f[v]; }
@@ -939,7 +939,7 @@ __global__ void reduce_inner2_k(const TT* __restrict__ T, int nchunk, int64_t tr
     for (; e < n; e += step) {
       RVec<TT, VEC> q0, p0;
       q0.load(Ta + e, FaT + e);
-      p0.t = *reinterpret_cast<const typename TVec<TT, VEC>::type*>(Tc + e);
+      p0.t = __builtin_nontemporal_load(reinterpret_cast<const typename TVec<TT, VEC>::type*>(Tc + e));
 #pragma unroll
       for (int v = 0; v < VEC; ++v) p0.f[v] = q0.f[v];
       q0.fma(a0); p0.fma(c0);

@@ -71,8 +71,8 @@ __global__ __launch_bounds__(kEmThreads) void em_cp_k(EmCpArgs a, double* ws) {
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
       const int64_t op = i0 + a.Ipad * (j0 + (p < nj ? p : nj - 1));
-      xq[p] = __builtin_nontemporal_load(reinterpret_cast<const XV*>(X + op));
-      mq[p] = __builtin_nontemporal_load(reinterpret_cast<const MV*>(M + op));
+      xq[p] = *reinterpret_cast<const XV*>(X + op);
+      mq[p] = *reinterpret_cast<const MV*>(M + op);
     }
     for (int jj = 0; jj < nj; ++jj) {
       const int64_t o = i0 + a.Ipad * (j0 + jj);
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(kEmThreads) void em_cp_k(EmCpArgs a, double* ws) {
       {
         const int jn = jj + PD < nj ? jj + PD : nj - 1;                  // clamped: the last loads are discarded
         const int64_t on = i0 + a.Ipad * (j0 + jn);
-        xq[PD - 1] = __builtin_nontemporal_load(reinterpret_cast<const XV*>(X + on));
-        mq[PD - 1] = __builtin_nontemporal_load(reinterpret_cast<const MV*>(M + on));
+        xq[PD - 1] = *reinterpret_cast<const XV*>(X + on);
+        mq[PD - 1] = *reinterpret_cast<const MV*>(M + on);
       }
       T m[VEC];
 #pragma unroll
@@ -114,9 +114,7 @@ __global__ __launch_bounds__(kEmThreads) void em_cp_k(EmCpArgs a, double* ws) {
           }
         }
       }
-      // streaming store: write-back stores left dirty lines in L2 whose evictions cut into the read stream (the same
-      // effect cost the tensor passes 0.4-1.1 ms per 2000^3 pass, contract.hip)
-      if (a.update && any_missing) __builtin_nontemporal_store(xv, reinterpret_cast<XV*>(X + o));
+      if (a.update && any_missing) *reinterpret_cast<XV*>(X + o) = xv;
     }
   }
   num = em_block_sum(num, sh4); den = em_block_sum(den, sh4);

@@ -5,6 +5,7 @@
 #include "device_utils.h"
 #include "em.h"
 #include "hosteig.h"
+#include "prox_dev.h"
 
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -1645,6 +1646,554 @@ __global__ void couple_dual_fin_k(double* out, const double* ws, int nb, const A
   out[threadIdx.x] = t;
 }
 
+// ---------------------------------------------------------------------------
+// The whole inner loop of a row-local coupling (types 0 and 4) in ONE launch, for the sizes the example scripts use
+// (rows of Delta up to a few thousand, ranks up to 16).  For these couplings every step of an inner iteration --
+// the primal solves of all coupled modes (:647-651, :925-929), the Delta update (:661-675, :939-963), the coupling
+// duals (:679, :967) and, with an element-/row-wise prox, update_constraint (:1420-1429) -- touches row i of every
+// matrix only, so thread i carries row i through the iteration without meeting another thread; the workgroup meets
+// once per iteration to add up the residual sums (:1099-1115, :1175-1191, :1079-1096) and to evaluate the while
+// condition (:630).  The launch-per-step form (couple_primal / couple_delta / couple_dual + constraint_update +
+// finalize: 12 launches per inner iteration for two constrained modes) is kept for larger problems.
+struct WgLoopMode {
+  const double* Aeff; const double* L; const double* rho; const double* H;
+  double *fac, *muD, *Z, *mu, *Zold;
+  double* slots;        // 8 residual sums of this mode (see FinalizeArgs)
+  int R, constrained, ptype;
+  double p0, p1;
+};
+struct WgLoopArgs {
+  WgLoopMode m[4];
+  int n, q, type, max_inner;
+  int64_t rows;
+  double *Delta, *DeltaOld, *dD;
+  const double* coefs;
+  const double* LAA;
+  double tol_pr_coupl, tol_pr_constr, tol_du_coupl, tol_du_constr;
+  AdmmCtl* ctl;
+};
+template <int RMAX>
+__global__ __launch_bounds__(256) void couple_loop_wg_k(WgLoopArgs a) {
+  extern __shared__ double sh[];                      // LAA (q*q) | per mode: L (R*R), H (q*R)
+  __shared__ double red[4][32];
+  __shared__ int go;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int q = a.q, type = a.type;
+  const int64_t rows = a.rows;
+  int offL[4], offH[4];
+  {
+    int off = q * q;
+    for (int j = 0; j < a.n; ++j) { offL[j] = off; off += a.m[j].R * a.m[j].R; offH[j] = off; off += q * a.m[j].R; }
+    if (type == 4)
+      for (int e = t; e < q * q; e += 256) sh[e] = a.LAA[e];
+    for (int j = 0; j < a.n; ++j) {
+      const int R = a.m[j].R;
+      for (int e = t; e < R * R; e += 256) sh[offL[j] + e] = a.m[j].L[e];
+      if (type == 4)
+        for (int e = t; e < q * R; e += 256) sh[offH[j] + e] = a.m[j].H[e];
+    }
+  }
+  if (t == 0) go = a.ctl->active;
+  __syncthreads();
+  int it = 0;
+  while (go) {
+    double sums[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sums[j][k] = 0.0;
+    for (int64_t i = t; i < rows; i += 256) {
+      double d[RMAX];
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) d[c] = c < q ? a.Delta[i + rows * c] : 0.0;
+      // ---- primal updates
+      for (int j = 0; j < a.n; ++j) {
+        const WgLoopMode& m = a.m[j];
+        const int R = m.R;
+        const double* Lsh = sh + offL[j];
+        const double* Hsh = sh + offH[j];
+        const double rh = m.rho[0] / 2;
+        double x[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+          x[r] = 0.0;
+          if (r < R) {
+            double td;
+            if (type == 4) {                          // (Delta*H)(i,r)  (:925)
+              td = 0.0;
+#pragma unroll
+              for (int c = 0; c < RMAX; ++c)
+                if (c < q) td += d[c] * Hsh[c + q * r];
+            } else {
+              td = d[r];                              // :647
+            }
+            double v = m.Aeff[i + rows * r] + rh * (td - m.muD[i + rows * r]);
+            if (m.constrained) v += rh * (m.Z[i + rows * r] - m.mu[i + rows * r]);
+            x[r] = v;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r)                // x * inv(L*L')  (:651, :929)
+          if (r < R) {
+            double v = x[r];
+#pragma unroll
+            for (int p = 0; p < RMAX; ++p)
+              if (p < r) v -= Lsh[r + R * p] * x[p];
+            x[r] = v / Lsh[r + R * r];
+          }
+#pragma unroll
+        for (int r = RMAX - 1; r >= 0; --r)
+          if (r < R) {
+            double v = x[r];
+#pragma unroll
+            for (int p = 0; p < RMAX; ++p)
+              if (p > r && p < R) v -= Lsh[p + R * r] * x[p];
+            x[r] = v / Lsh[r + R * r];
+          }
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r)
+          if (r < R) m.fac[i + rows * r] = x[r];
+      }
+      // ---- Delta
+      double bb[RMAX];
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) bb[c] = 0.0;
+      for (int j = 0; j < a.n; ++j) {
+        const WgLoopMode& m = a.m[j];
+        if (type == 4) {
+          const double rj = m.rho[0];
+          double tt[RMAX];
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) tt[r] = r < m.R ? m.fac[i + rows * r] + m.muD[i + rows * r] : 0.0;
+          const double* Hj = sh + offH[j];
+#pragma unroll
+          for (int c = 0; c < RMAX; ++c)
+            if (c < q) {
+              double acc = 0.0;
+#pragma unroll
+              for (int r = 0; r < RMAX; ++r)
+                if (r < m.R) acc += tt[r] * Hj[c + q * r];
+              bb[c] = (j == 0 ? 0.0 : bb[c]) + rj * acc;                           // :955
+            }
+        } else {
+          const double cj = a.coefs[j];               // rho_j / sum rho
+#pragma unroll
+          for (int c = 0; c < RMAX; ++c)
+            if (c < q) {
+              const double v = cj * m.fac[i + rows * c] + cj * m.muD[i + rows * c];
+              bb[c] = j == 0 ? v : bb[c] + v;
+            }
+        }
+      }
+      if (type == 4) {                                // Delta(i,:) = bb * inv(LAA*LAA')
+        const double* Lsh = sh;
+#pragma unroll
+        for (int c = 0; c < RMAX; ++c)
+          if (c < q) {
+            double v = bb[c];
+#pragma unroll
+            for (int p = 0; p < RMAX; ++p)
+              if (p < c) v -= Lsh[c + q * p] * bb[p];
+            bb[c] = v / Lsh[c + q * c];
+          }
+#pragma unroll
+        for (int c = RMAX - 1; c >= 0; --c)
+          if (c < q) {
+            double v = bb[c];
+#pragma unroll
+            for (int p = 0; p < RMAX; ++p)
+              if (p > c && p < q) v -= Lsh[p + q * c] * bb[p];
+            bb[c] = v / Lsh[c + q * c];
+          }
+      }
+      double dd[RMAX];
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) {
+        dd[c] = 0.0;
+        if (c < q) {
+          a.DeltaOld[i + rows * c] = d[c];
+          a.Delta[i + rows * c] = bb[c];
+          dd[c] = bb[c] - d[c];
+          a.dD[i + rows * c] = dd[c];
+        }
+      }
+      // ---- coupling duals, constraints, residual sums
+      for (int j = 0; j < a.n; ++j) {
+        const WgLoopMode& m = a.m[j];
+        const int R = m.R;
+        const double* Hsh = sh + offH[j];
+        double f[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+          f[r] = 0.0;
+          if (r < R) {
+            double td, tdd;
+            if (type == 4) {
+              td = 0.0; tdd = 0.0;
+#pragma unroll
+              for (int c = 0; c < RMAX; ++c)
+                if (c < q) { td += bb[c] * Hsh[c + q * r]; tdd += dd[c] * Hsh[c + q * r]; }
+            } else { td = bb[r]; tdd = dd[r]; }
+            f[r] = m.fac[i + rows * r];
+            const double g = f[r] - td;
+            const double mm = m.muD[i + rows * r] + g;                              // :679, :967
+            m.muD[i + rows * r] = mm;
+            sums[j][4] += g * g; sums[j][5] += mm * mm; sums[j][6] += tdd * tdd; sums[j][7] += f[r] * f[r];
+          }
+        }
+        if (m.constrained) {                          // update_constraint (:1420-1429)
+          const double rho = m.rho[0];
+          double zo[RMAX], mu[RMAX], z[RMAX];
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) {
+            zo[r] = r < R ? m.Z[i + rows * r] : 0.0;
+            mu[r] = r < R ? m.mu[i + rows * r] : 0.0;
+            z[r] = f[r] + mu[r];
+          }
+          if (m.ptype == AOADMM_C_SIMPLEX_ROW) {
+            simplex_regs<RMAX>(z, R, m.p0);
+          } else {
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) z[r] = prox_elem(m.ptype, z[r], m.p0, m.p1, rho);
+          }
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r)
+            if (r < R) {
+              const double mn = mu[r] + f[r] - z[r];
+              m.Zold[i + rows * r] = zo[r];
+              m.Z[i + rows * r] = z[r];
+              m.mu[i + rows * r] = mn;
+              const double dz = z[r] - zo[r];
+              sums[j][0] += (f[r] - z[r]) * (f[r] - z[r]); sums[j][1] += f[r] * f[r]; sums[j][2] += mn * mn; sums[j][3] += dz * dz;
+            }
+        } else {
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) sums[j][1] += f[r] * f[r];
+        }
+      }
+    }
+    // ---- the workgroup's sums (fixed order: lanes by butterfly, then the four waves in order)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        double v = sums[j][k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[w][j * 8 + k] = v;
+      }
+    __syncthreads();
+    if (t < 32) {
+      const double tot = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+      red[0][t] = tot;
+      const int j = t >> 3;
+      if (j < a.n) a.m[j].slots[t & 7] = tot;
+    }
+    __syncthreads();
+    if (t == 0) {                                     // eval_res_ADMM_coupl_case0/4 + eval_res_ADMM_constr, while condition
+      double prc = 0, duc = 0, prz = 0, duz = 0;
+      int nz = 0;
+      for (int j = 0; j < a.n; ++j) {
+        const double* sj = &red[0][j * 8];
+        prc += sqrt(sj[4]) / sqrt(sj[7]);
+        const double sc = sqrt(sj[5]);
+        duc += sc > 0 ? sqrt(sj[6]) / sc : sqrt(sj[6]);
+        if (a.m[j].constrained) {
+          prz += sqrt(sj[0]) / sqrt(sj[1]);
+          const double sz = sqrt(sj[2]);
+          duz += sz > 0 ? sqrt(sj[3]) / sz : sqrt(sj[3]);
+          ++nz;
+        }
+      }
+      prc /= a.n; duc /= a.n;
+      if (nz) { prz /= nz; duz /= nz; }
+      ++it;
+      a.ctl->res[0] = prc; a.ctl->res[1] = prz; a.ctl->res[2] = duc; a.ctl->res[3] = duz;
+      a.ctl->iters = it;
+      const int cont = (it < a.max_inner && (prc > a.tol_pr_coupl || prz > a.tol_pr_constr || duc > a.tol_du_coupl ||
+                                             duz > a.tol_du_constr)) ? 1 : 0;
+      a.ctl->active = cont;
+      go = cont;
+    }
+    __syncthreads();
+  }
+}
+
+// Register-resident form of couple_loop_wg_k for rows <= 256 (one row per thread) and NM coupled modes: the rows of A,
+// fac, mu_Delta, Z, mu of every coupled mode and the row of Delta are loaded once, live in registers for the whole
+// loop and are stored once.  An inner iteration is then arithmetic plus one workgroup reduction, with no memory round
+// trip (the global-memory form re-reads its own stores from L2 several times per iteration: 25 us per iteration
+// against a few us here at 50 rows x 4 columns).
+template <int RMAX, int NM>
+__global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
+  extern __shared__ double sh[];                      // LAA (q*q) | per mode: L (R*R), H (q*R)
+  __shared__ double red[4][8 * NM];
+  __shared__ int go;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int q = a.q, type = a.type;
+  const int64_t rows = a.rows;
+  const int64_t i = t;
+  const bool have = i < rows;
+  const int64_t ic = have ? i : rows - 1;             // clamped: padding threads compute on a valid row, store nothing
+  int offL[NM], offH[NM];
+  {
+    int off = q * q;
+#pragma unroll
+    for (int j = 0; j < NM; ++j) { offL[j] = off; off += a.m[j].R * a.m[j].R; offH[j] = off; off += q * a.m[j].R; }
+    if (type == 4)
+      for (int e = t; e < q * q; e += 256) sh[e] = a.LAA[e];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+      const int R = a.m[j].R;
+      for (int e = t; e < R * R; e += 256) sh[offL[j] + e] = a.m[j].L[e];
+      if (type == 4)
+        for (int e = t; e < q * R; e += 256) sh[offH[j] + e] = a.m[j].H[e];
+    }
+  }
+  double d[RMAX], av[NM][RMAX], f[NM][RMAX], md[NM][RMAX], z[NM][RMAX], mu[NM][RMAX], zo[NM][RMAX], rh[NM], rho[NM];
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c) d[c] = c < q ? a.Delta[ic + rows * c] : 0.0;
+#pragma unroll
+  for (int j = 0; j < NM; ++j) {
+    const WgLoopMode& m = a.m[j];
+    rho[j] = m.rho[0];
+    rh[j] = rho[j] / 2;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const bool ok = r < m.R;
+      const int64_t o = ic + rows * (ok ? r : 0);
+      av[j][r] = ok ? m.Aeff[o] : 0.0;
+      f[j][r] = ok ? m.fac[o] : 0.0;
+      md[j][r] = ok ? m.muD[o] : 0.0;
+      z[j][r] = (ok && m.constrained) ? m.Z[o] : 0.0;
+      mu[j][r] = (ok && m.constrained) ? m.mu[o] : 0.0;
+      zo[j][r] = z[j][r];
+    }
+  }
+  double dold[RMAX], dd[RMAX];
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c) { dold[c] = d[c]; dd[c] = 0.0; }
+  if (t == 0) go = a.ctl->active;
+  __syncthreads();
+  int it = 0;
+  bool ran = false;
+  while (go) {
+    ran = true;
+    double sums[NM][8];
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sums[j][k] = 0.0;
+    // ---- primal updates
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+      const WgLoopMode& m = a.m[j];
+      const int R = m.R;
+      const double* Lsh = sh + offL[j];
+      const double* Hsh = sh + offH[j];
+      double x[RMAX];
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        x[r] = 0.0;
+        if (r < R) {
+          double td;
+          if (type == 4) {                            // (Delta*H)(i,r)  (:925)
+            td = 0.0;
+#pragma unroll
+            for (int c = 0; c < RMAX; ++c)
+              if (c < q) td += d[c] * Hsh[c + q * r];
+          } else {
+            td = d[r];                                // :647
+          }
+          double v = av[j][r] + rh[j] * (td - md[j][r]);
+          if (m.constrained) v += rh[j] * (z[j][r] - mu[j][r]);
+          x[r] = v;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r)                  // x * inv(L*L')  (:651, :929)
+        if (r < R) {
+          double v = x[r];
+#pragma unroll
+          for (int p = 0; p < RMAX; ++p)
+            if (p < r) v -= Lsh[r + R * p] * x[p];
+          x[r] = v / Lsh[r + R * r];
+        }
+#pragma unroll
+      for (int r = RMAX - 1; r >= 0; --r)
+        if (r < R) {
+          double v = x[r];
+#pragma unroll
+          for (int p = 0; p < RMAX; ++p)
+            if (p > r && p < R) v -= Lsh[p + R * r] * x[p];
+          x[r] = v / Lsh[r + R * r];
+        }
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) f[j][r] = r < R ? x[r] : 0.0;
+    }
+    // ---- Delta
+    double bb[RMAX];
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) bb[c] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+      const WgLoopMode& m = a.m[j];
+      if (type == 4) {
+        const double* Hj = sh + offH[j];
+#pragma unroll
+        for (int c = 0; c < RMAX; ++c)
+          if (c < q) {
+            double acc = 0.0;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r)
+              if (r < m.R) acc += (f[j][r] + md[j][r]) * Hj[c + q * r];
+            bb[c] = (j == 0 ? 0.0 : bb[c]) + rho[j] * acc;                         // :955
+          }
+      } else {
+        const double cj = a.coefs[j];                 // rho_j / sum rho
+#pragma unroll
+        for (int c = 0; c < RMAX; ++c)
+          if (c < q) {
+            const double v = cj * f[j][c] + cj * md[j][c];
+            bb[c] = j == 0 ? v : bb[c] + v;
+          }
+      }
+    }
+    if (type == 4) {                                  // Delta(i,:) = bb * inv(LAA*LAA')
+      const double* Lsh = sh;
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c)
+        if (c < q) {
+          double v = bb[c];
+#pragma unroll
+          for (int p = 0; p < RMAX; ++p)
+            if (p < c) v -= Lsh[c + q * p] * bb[p];
+          bb[c] = v / Lsh[c + q * c];
+        }
+#pragma unroll
+      for (int c = RMAX - 1; c >= 0; --c)
+        if (c < q) {
+          double v = bb[c];
+#pragma unroll
+          for (int p = 0; p < RMAX; ++p)
+            if (p > c && p < q) v -= Lsh[p + q * c] * bb[p];
+          bb[c] = v / Lsh[c + q * c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) {
+      dold[c] = d[c];
+      dd[c] = c < q ? bb[c] - d[c] : 0.0;
+      d[c] = c < q ? bb[c] : 0.0;
+    }
+    // ---- coupling duals, constraints, residual sums
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+      const WgLoopMode& m = a.m[j];
+      const int R = m.R;
+      const double* Hsh = sh + offH[j];
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r)
+        if (r < R) {
+          double td, tdd;
+          if (type == 4) {
+            td = 0.0; tdd = 0.0;
+#pragma unroll
+            for (int c = 0; c < RMAX; ++c)
+              if (c < q) { td += d[c] * Hsh[c + q * r]; tdd += dd[c] * Hsh[c + q * r]; }
+          } else { td = d[r]; tdd = dd[r]; }
+          const double g = f[j][r] - td;
+          const double mm = md[j][r] + g;                                           // :679, :967
+          md[j][r] = mm;
+          if (have) { sums[j][4] += g * g; sums[j][5] += mm * mm; sums[j][6] += tdd * tdd; sums[j][7] += f[j][r] * f[j][r]; }
+        }
+      if (m.constrained) {                            // update_constraint (:1420-1429)
+        double zn[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) { zo[j][r] = z[j][r]; zn[r] = f[j][r] + mu[j][r]; }
+        if (m.ptype == AOADMM_C_SIMPLEX_ROW) {
+          simplex_regs<RMAX>(zn, R, m.p0);
+        } else {
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) zn[r] = prox_elem(m.ptype, zn[r], m.p0, m.p1, rho[j]);
+        }
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r)
+          if (r < R) {
+            const double mn = mu[j][r] + f[j][r] - zn[r];
+            const double dz = zn[r] - zo[j][r];
+            if (have) {
+              sums[j][0] += (f[j][r] - zn[r]) * (f[j][r] - zn[r]); sums[j][1] += f[j][r] * f[j][r]; sums[j][2] += mn * mn;
+              sums[j][3] += dz * dz;
+            }
+            z[j][r] = zn[r];
+            mu[j][r] = mn;
+          }
+      } else if (have) {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) sums[j][1] += f[j][r] * f[j][r];
+      }
+    }
+    // ---- the workgroup's sums (fixed order: lanes by butterfly, then the four waves in order)
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        double v = sums[j][k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[w][j * 8 + k] = v;
+      }
+    __syncthreads();
+    if (t < 8 * NM) {
+      const double tot = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+      red[0][t] = tot;
+      a.m[t >> 3].slots[t & 7] = tot;
+    }
+    __syncthreads();
+    if (t == 0) {                                     // eval_res_ADMM_coupl_case0/4 + eval_res_ADMM_constr, while condition
+      double prc = 0, duc = 0, prz = 0, duz = 0;
+      int nz = 0;
+      for (int j = 0; j < NM; ++j) {
+        const double* sj = &red[0][j * 8];
+        prc += sqrt(sj[4]) / sqrt(sj[7]);
+        const double sc = sqrt(sj[5]);
+        duc += sc > 0 ? sqrt(sj[6]) / sc : sqrt(sj[6]);
+        if (a.m[j].constrained) {
+          prz += sqrt(sj[0]) / sqrt(sj[1]);
+          const double sz = sqrt(sj[2]);
+          duz += sz > 0 ? sqrt(sj[3]) / sz : sqrt(sj[3]);
+          ++nz;
+        }
+      }
+      prc /= NM; duc /= NM;
+      if (nz) { prz /= nz; duz /= nz; }
+      ++it;
+      a.ctl->res[0] = prc; a.ctl->res[1] = prz; a.ctl->res[2] = duc; a.ctl->res[3] = duz;
+      a.ctl->iters = it;
+      const int cont = (it < a.max_inner && (prc > a.tol_pr_coupl || prz > a.tol_pr_constr || duc > a.tol_du_coupl ||
+                                             duz > a.tol_du_constr)) ? 1 : 0;
+      a.ctl->active = cont;
+      go = cont;
+    }
+    __syncthreads();
+  }
+  if (!ran || !have) return;
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c)
+    if (c < q) { a.Delta[i + rows * c] = d[c]; a.DeltaOld[i + rows * c] = dold[c]; a.dD[i + rows * c] = dd[c]; }
+#pragma unroll
+  for (int j = 0; j < NM; ++j) {
+    const WgLoopMode& m = a.m[j];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (r < m.R) {
+        const int64_t o = i + rows * r;
+        m.fac[o] = f[j][r];
+        m.muD[o] = md[j][r];
+        if (m.constrained) { m.Z[o] = z[j][r]; m.mu[o] = mu[j][r]; m.Zold[o] = zo[j][r]; }
+      }
+  }
+}
+
 void Engine::coupled_admm(int c, const aoadmm_options& opt) {
   CouplingInfo& ci = couplings_[c];
   AdmmCtl* ctl = ctl_of_coupling(c);
@@ -1733,6 +2282,41 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
         else if (rmax <= 8) launch(std::integral_constant<int, 8>());
         else launch(std::integral_constant<int, 16>());
       };
+      // small problems: the whole loop in one launch of one workgroup (couple_loop_wg_k)
+      bool local_prox = true;
+      for (int j = 0; j < n; ++j) {
+        const ModeInfo& mi = modes_[ci.modes[j]];
+        local_prox = local_prox && (!mi.constrained || prox_is_fusable(mi.prox.type));
+      }
+      static const bool no_wg = getenv("AOADMM_NO_WG_LOOP") != nullptr;           // development switch
+      if (n <= 4 && rows <= 2048 && local_prox && !no_wg) {
+        WgLoopArgs wa;
+        wa.n = n; wa.q = q; wa.type = ty; wa.max_inner = opt.MaxInnerIters; wa.rows = rows;
+        wa.Delta = ci.Delta.d(); wa.DeltaOld = ci.DeltaOld.d(); wa.dD = ci.dD.d(); wa.coefs = ci.coef.d(); wa.LAA = ci.LAA.d();
+        wa.tol_pr_coupl = opt.innerRelPrTol_coupl; wa.tol_pr_constr = opt.innerRelPrTol_constr;
+        wa.tol_du_coupl = opt.innerRelDualTol_coupl; wa.tol_du_constr = opt.innerRelDualTol_constr;
+        wa.ctl = ctl;
+        size_t lds = (size_t)q * q;
+        for (int j = 0; j < n; ++j) {
+          ModeInfo& mi = modes_[ci.modes[j]];
+          WgLoopMode& wm = wa.m[j];
+          wm.Aeff = mi.Aeff; wm.L = mi.L.d(); wm.rho = mi.rho.d(); wm.H = ty == 4 ? mi.H.d() : nullptr;
+          wm.fac = mi.fac.d(); wm.muD = mi.muD.d(); wm.Z = mi.Z.d(); wm.mu = mi.mu.d(); wm.Zold = mi.Zold.d();
+          wm.slots = resid + (int64_t)ci.modes[j] * kResidPerMode;
+          wm.R = mi.R; wm.constrained = mi.constrained ? 1 : 0; wm.ptype = mi.prox.type; wm.p0 = mi.prox.p0; wm.p1 = mi.prox.p1;
+          lds += (size_t)mi.R * mi.R + (size_t)q * mi.R;
+        }
+        if (rows <= 256 && rmax <= 8 && n <= 3) {     // one row per thread: the state stays in registers
+#define AO_WGR(RM, NMM) couple_loop_wg_regs_k<RM, NMM><<<1, 256, lds * sizeof(double), stream_>>>(wa)
+          if (rmax <= 4) { if (n == 1) AO_WGR(4, 1); else if (n == 2) AO_WGR(4, 2); else AO_WGR(4, 3); }
+          else { if (n == 1) AO_WGR(8, 1); else if (n == 2) AO_WGR(8, 2); else AO_WGR(8, 3); }
+#undef AO_WGR
+        } else {
+          by_rmax([&](auto tag) { couple_loop_wg_k<decltype(tag)::value><<<1, 256, lds * sizeof(double), stream_>>>(wa); });
+        }
+        AO_KERNEL_CHECK();
+        return;
+      }
       for (int it = 0; it < opt.MaxInnerIters; ++it) {
         for (int j = 0; j < n; ++j) {                 // primal: Sd(Delta), right-hand side and row solve in one kernel
           const size_t lds = ((size_t)rc[j].R * rc[j].R + (size_t)q * rc[j].R) * sizeof(double);

@@ -39,10 +39,10 @@ def cp_model(dims, R, rng, constraints, noise=0.05, weight=1.0):
     return Z, io, A
 
 
-def script3_model(rng, noise=0.05):
+def script3_model(rng, noise=0.05, rows=50):
     """example_script3_matrix_CP_partialcoupling_nonneg.m:23-68: CP 50x30x40 R=4 + matrix 50x70 R=3,
-    modes 1 and 4 coupled with type 4 (C = Delta*H), H1 = eye(4), H4 = [eye(3); 0 0 0]."""
-    D = rng.random((50, 4))
+    modes 1 and 4 coupled with type 4 (C = Delta*H), H1 = eye(4), H4 = [eye(3); 0 0 0].  `rows`: length of the coupled mode."""
+    D = rng.random((rows, 4))
     A = [D, rng.standard_normal((30, 4)), rng.standard_normal((40, 4))]
     M = [D[:, :3], rng.random((70, 3))]
     X1 = full_ktensor(A)
@@ -55,7 +55,7 @@ def script3_model(rng, noise=0.05):
     H = [None] * 5
     H[0] = np.eye(4)
     H[3] = np.vstack([np.eye(3), np.zeros((1, 3))])
-    Z = dict(loss_function=['Frobenius'] * 2, model=['CP', 'CP'], modes=[[1, 2, 3], [4, 5]], size=[50, 30, 40, 50, 70],
+    Z = dict(loss_function=['Frobenius'] * 2, model=['CP', 'CP'], modes=[[1, 2, 3], [4, 5]], size=[rows, 30, 40, rows, 70],
              coupling=dict(lin_coupled_modes=[1, 0, 0, 1, 0], coupling_type=[4], coupl_trafo_matrices=H),
              constrained_modes=[1, 0, 0, 1, 1],
              constraints=[('non-negativity',), None, None, ('non-negativity',), ('non-negative l2-sphere', 1)],
@@ -66,10 +66,10 @@ def script3_model(rng, noise=0.05):
     return Z, io
 
 
-def cp_cp_exact_model(rng, noise=0.05):
+def cp_cp_exact_model(rng, noise=0.05, rows=24):
     """Two CP tensors sharing their first factor exactly (coupling type 0), non-negative first modes."""
     R = 3
-    D = rng.random((24, R))
+    D = rng.random((rows, R))
     A = [D, rng.standard_normal((18, R)), rng.random((20, R))]
     B = [D, rng.random((16, R)), rng.standard_normal((14, R))]
     X1 = full_ktensor(A)
@@ -80,7 +80,7 @@ def cp_cp_exact_model(rng, noise=0.05):
     X1 /= np.linalg.norm(X1)
     X2 /= np.linalg.norm(X2)
     Z = dict(loss_function=['Frobenius'] * 2, model=['CP', 'CP'], modes=[[1, 2, 3], [4, 5, 6]],
-             size=[24, 18, 20, 24, 16, 14],
+             size=[rows, 18, 20, rows, 16, 14],
              coupling=dict(lin_coupled_modes=[1, 0, 0, 1, 0, 0], coupling_type=[0], coupl_trafo_matrices=[None] * 6),
              constrained_modes=[1, 0, 1, 1, 1, 0],
              constraints=[('non-negativity',), None, ('non-negativity',), ('non-negativity',), ('box', 0.0, 2.0), None],

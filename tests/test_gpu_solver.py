@@ -68,6 +68,29 @@ def test_cp_cp_exact_coupling(pkg, eng):
     compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=15)))
 
 
+@pytest.mark.parametrize('rows', [300, 2500])
+@pytest.mark.parametrize('ctype', [0, 4])
+def test_row_local_coupling_loop_forms(pkg, eng, rows, ctype):
+    """The three forms of the row-local coupled loop (csrc/solver.hip): register-resident one-workgroup kernel (rows
+    <= 256: the script-sized tests above), global-memory one-workgroup kernel (300 rows here), one launch per step
+    (2500 rows), for the exact (type 0) and the partial (type 4) coupling."""
+    rng = np.random.default_rng(40 + ctype)
+    Z, io = (cp_cp_exact_model(rng, rows=rows) if ctype == 0 else script3_model(rng, rows=rows))
+    compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=6)))
+
+
+def test_coupled_loop_early_exit_matches(pkg, eng):
+    """Non-zero inner tolerances on a coupled model: the one-workgroup loop stops after the same inner iteration as the
+    oracle's ADMM_coupled_case4 (innerIters compared), and the state it leaves is the state of that iteration."""
+    rng = np.random.default_rng(44)
+    Z, io = script3_model(rng)
+    opt = options(MaxOuterIters=25, MaxInnerIters=10, innerRelPrTol_coupl=1e-2, innerRelDualTol_coupl=1e-2,
+                  innerRelPrTol_constr=1e-2, innerRelDualTol_constr=1e-2)
+    Fo, oo, Fg, og = run_both(pkg, eng, Z, io, opt)
+    assert np.array_equal(og['innerIters'], oo['innerIters'])
+    compare(Fo, oo, Fg, og)
+
+
 def test_early_stop_matches(pkg, eng):
     """Non-zero tolerances: inner/outer stopping decisions taken on the device agree with the oracle."""
     rng = np.random.default_rng(6)

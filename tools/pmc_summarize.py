@@ -20,7 +20,7 @@ fetch, nf = collect('fetch'); write, nw = collect('write'); tcc, nt = collect('t
 raw = fetch['FETCH_SIZE']
 unit = 1024.0 if raw < 1e9 else 1.0          # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB on some versions
 res = {
-    'kernel': kname, 'workload': '2000^3 R=20 fp32, one tensor pass (tools/perf_mttkrp.py)',
+    'kernel': kname, 'workload': '2000^3 R=20, one tensor pass of %s (tools/perf_mttkrp.py, PREC=%s)' % (kname, os.environ.get('PREC', 'f32')),
     'source': 'rocprofv3 --pmc (separate passes), tools/pmc_contract.sh',
     'FETCH_SIZE_bytes_raw': raw * unit, 'FETCH_SIZE_bytes_corrected_x2': 2 * raw * unit,
     'WRITE_SIZE_bytes': write['WRITE_SIZE'] * unit,
