@@ -1927,6 +1927,7 @@ template <int RMAX, int NM>
 __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
   extern __shared__ double sh[];                      // LAA (q*q) | per mode: L (R*R), H (q*R)
   __shared__ double red[4][8 * NM];
+  __shared__ double invd[NM + 1][RMAX];               // reciprocal diagonals of L_j and of LAA: the substitutions multiply
   __shared__ int go;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int q = a.q, type = a.type;
@@ -1948,6 +1949,12 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
       if (type == 4)
         for (int e = t; e < q * R; e += 256) sh[offH[j] + e] = a.m[j].H[e];
     }
+  }
+  __syncthreads();
+  if (t < RMAX) {
+#pragma unroll
+    for (int j = 0; j < NM; ++j) invd[j][t] = t < a.m[j].R ? 1.0 / sh[offL[j] + t + a.m[j].R * t] : 0.0;
+    invd[NM][t] = (type == 4 && t < q) ? 1.0 / sh[t + q * t] : 0.0;
   }
   double d[RMAX], av[NM][RMAX], f[NM][RMAX], md[NM][RMAX], z[NM][RMAX], mu[NM][RMAX], zo[NM][RMAX], rh[NM], rho[NM];
 #pragma unroll
@@ -2016,7 +2023,7 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
 #pragma unroll
           for (int p = 0; p < RMAX; ++p)
             if (p < r) v -= Lsh[r + R * p] * x[p];
-          x[r] = v / Lsh[r + R * r];
+          x[r] = v * invd[j][r];
         }
 #pragma unroll
       for (int r = RMAX - 1; r >= 0; --r)
@@ -2025,7 +2032,7 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
 #pragma unroll
           for (int p = 0; p < RMAX; ++p)
             if (p > r && p < R) v -= Lsh[p + R * r] * x[p];
-          x[r] = v / Lsh[r + R * r];
+          x[r] = v * invd[j][r];
         }
 #pragma unroll
       for (int r = 0; r < RMAX; ++r) f[j][r] = r < R ? x[r] : 0.0;
@@ -2067,7 +2074,7 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
 #pragma unroll
           for (int p = 0; p < RMAX; ++p)
             if (p < c) v -= Lsh[c + q * p] * bb[p];
-          bb[c] = v / Lsh[c + q * c];
+          bb[c] = v * invd[NM][c];
         }
 #pragma unroll
       for (int c = RMAX - 1; c >= 0; --c)
@@ -2076,7 +2083,7 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
 #pragma unroll
           for (int p = 0; p < RMAX; ++p)
             if (p > c && p < q) v -= Lsh[p + q * c] * bb[p];
-          bb[c] = v / Lsh[c + q * c];
+          bb[c] = v * invd[NM][c];
         }
     }
 #pragma unroll
