@@ -25,6 +25,7 @@ struct SynthArgs {
   int64_t I_loc, I_pad, J, K, row0, I_full;
   int R;
   uint64_t seed;
+  int64_t k0 = 0, K_loc = -1;    // third-mode slab [k0, k0 + K_loc) of the block (K_loc < 0: all of it)
 };
 void synth_factors(double* A, double* B, double* C, const SynthArgs& a, hipStream_t s);   // fp64 col-major, full sizes
 void synth_norms(double* out3, const double* A, const double* B, const double* C, const SynthArgs& a,

@@ -158,9 +158,11 @@ __global__ void synth_k(T* X, double* ws, const double* A, const double* B, cons
   __shared__ double bc[kMaxRank];
   __shared__ double sh[256];
   double s_cc = 0, s_nn = 0, s_cn = 0;
-  const int64_t ncol = a.J * a.K;
-  for (int64_t col = blockIdx.x; col < ncol; col += gridDim.x) {
-    const int64_t j = col % a.J, k = col / a.J;
+  const int64_t Kl = a.K_loc < 0 ? a.K : a.K_loc;
+  const int64_t ncol = a.J * Kl;
+  for (int64_t lcol = blockIdx.x; lcol < ncol; lcol += gridDim.x) {
+    const int64_t j = lcol % a.J, k = lcol / a.J + a.k0;
+    const int64_t col = j + a.J * k;                 // global column: the noise stream is indexed by global position
     __syncthreads();
     if ((int)threadIdx.x < a.R) bc[threadIdx.x] = B[j + a.J * threadIdx.x] * C[k + a.K * threadIdx.x];
     __syncthreads();
@@ -174,7 +176,7 @@ __global__ void synth_k(T* X, double* ws, const double* A, const double* B, cons
       if (PASS == 1) {
         s_cc += clean * clean; s_nn += nz * nz; s_cn += clean * nz;
       } else {
-        X[i + a.I_pad * col] = (T)((clean + sigma * nz) * inv_norm);
+        X[i + a.I_pad * lcol] = (T)((clean + sigma * nz) * inv_norm);
       }
     }
   }

@@ -36,6 +36,11 @@ struct CpBlock {
   DevBuf emkr, emkr2;  // order > 3 with Z.miss: Khatri-Rao factor of the merged trailing modes (ping-pong)
   int64_t Jp = 0;
   bool has_xp = false, xp_refused = false;
+  // With a communicator the copy for the pass that contracts mode 1 is sharded along mode 3 instead of mode 1:
+  // rank g holds X(:, :, K_g), contracts ALL of mode 1 and gets a complete T(j, k in K_g, r) of 1/N the size, instead
+  // of a partial sum of full size J x K from its rows of mode 1.
+  bool xp_ksharded = false;
+  int64_t xp_k0 = 0, xp_kloc = 0;
   // third copy Xq(k,i,j) = X(i,j,k) (leading dimension Kp): the pass that contracts mode 2 then streams like the
   // other two instead of running K batches of an I x J matrix (measured 6.0 ms against 5.4-5.5 ms at 2000^3)
   DevBuf Xq;
@@ -215,14 +220,18 @@ class Engine {
   bool ensure_permuted_copy(CpBlock& b);
   bool ensure_permuted_copy2(CpBlock& b);
   bool ensure_blocked_copy(CpBlock& b);
+  // builds the mode-3-sharded Xp from a natural-layout slab X(:, :, [k0, k0 + kloc)) already on the device
+  void adopt_ksharded_xp(CpBlock& b, const void* slab, int64_t k0, int64_t kloc);
+  bool want_ksharded_xp(const CpBlock& b, int64_t K, int64_t* k0, int64_t* kloc) const;
   void drop_permuted_copies(CpBlock& b);
   bool prefetch_next_contraction(const aoadmm_options& opt);   // true: a tensor pass was enqueued
   // `collective` = false: the block holds the whole tensor and the result is complete on this engine (op-level
   // entry on an engine that happens to belong to a communicator)
   void block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
                     int64_t ldOut, bool use_cache, const int* update_seq, int nseq, bool collective = true);
+  // `full_array`: the caller's whole tensor when it holds one (lets a sharded engine take its mode-3 slab as well)
   void block_upload(CpBlock& b, int nd, const int64_t* dims, const double* host, int prec, int64_t row0,
-                    int64_t local_rows);
+                    int64_t local_rows, const double* full_array = nullptr);
   void allreduce(double* buf, int64_t n);
   double* scratch_slots() { return slots_.d(); }
   double* red_ws() { return redws_.d(); }

@@ -463,9 +463,10 @@ void Engine::model_end() {
 // data
 // ---------------------------------------------------------------------------
 static int64_t pad_of(int prec, int64_t n) { return round_up(n, prec == AOADMM_PREC_F32 ? 4 : 2); }
+static size_t blocked_bytes(int64_t M, int64_t C, size_t es) { return (size_t)round_up(M, kRowBlockElems) * C * es; }
 
 void Engine::block_upload(CpBlock& b, int nd, const int64_t* dims, const double* host, int prec, int64_t row0,
-                          int64_t local_rows) {
+                          int64_t local_rows, const double* full_array) {
   AO_REQUIRE(nd >= 2 && nd <= 8, "tensor order %d unsupported", nd);
   AO_REQUIRE(prec == AOADMM_PREC_F64 || prec == AOADMM_PREC_F32, "bad precision id %d", prec);
   AO_REQUIRE(row0 >= 0 && local_rows > 0 && row0 + local_rows <= dims[0], "bad row block [%lld,+%lld) of %lld",
@@ -506,6 +507,27 @@ void Engine::block_upload(CpBlock& b, int nd, const int64_t* dims, const double*
   b.has_data = true;
   b.cached_mode = -1;
   b.has_xp = false; b.xp_refused = false; b.has_xq = false; b.xq_refused = false; b.has_xc = false; b.xc_refused = false;
+  b.xp_ksharded = false;
+  if (nd == 3 && full_array != nullptr) {             // the caller holds the whole tensor: mode-3 slab for the mode-1 pass
+    int64_t k0 = 0, kloc = 0;
+    if (want_ksharded_xp(b, dims[2], &k0, &kloc)) {
+      const int64_t I = dims[0], J = dims[1], Ipf = pad_of(prec, I);
+      DevBuf slab;
+      slab.alloc((size_t)Ipf * J * kloc * b.X.elem_size());
+      const double* src = full_array + (size_t)I * J * k0;      // X(:, :, k0 : k0+kloc) is contiguous
+      const int64_t ncs = J * kloc;
+      const int64_t cc = std::max<int64_t>(1, (int64_t)(64ll << 20) / I);
+      staging_.ensure((size_t)std::min(cc, ncs) * I * sizeof(double));
+      for (int64_t c0 = 0; c0 < ncs; c0 += cc) {
+        const int64_t nc = std::min(cc, ncs - c0);
+        AO_HIP(hipMemcpyAsync(staging_.p, src + c0 * I, (size_t)nc * I * sizeof(double), hipMemcpyHostToDevice, stream_));
+        pad_convert(slab.p, prec, Ipf, staging_.d(), I, nc, c0, stream_);
+        AO_HIP(hipStreamSynchronize(stream_));
+      }
+      adopt_ksharded_xp(b, slab.p, k0, kloc);
+      AO_HIP(hipStreamSynchronize(stream_));          // slab is a local
+    }
+  }
   if (nd == 3) { (void)ensure_permuted_copy2(b); (void)ensure_blocked_copy(b); }   // one-off set-up cost belongs to the upload
 }
 
@@ -532,7 +554,7 @@ void Engine::tensor_upload(int p, const double* data, int prec, int64_t row0, in
       std::vector<double> blk((size_t)local_rows * ncols);
       for (int64_t c = 0; c < ncols; ++c)
         std::memcpy(&blk[(size_t)c * local_rows], data + c * I + row0, (size_t)local_rows * sizeof(double));
-      block_upload(t.blk, t.nmodes, dims, blk.data(), prec, row0, local_rows);
+      block_upload(t.blk, t.nmodes, dims, blk.data(), prec, row0, local_rows, data);
     }
   } else {
     block_upload(t.blk, t.nmodes, dims, data, prec, row0, local_rows);
@@ -620,6 +642,19 @@ void Engine::tensor_synth(int p, int rank, uint64_t seed, double noise, int prec
   b.has_data = true;
   b.cached_mode = -1;
   b.has_xp = false; b.xp_refused = false; b.has_xq = false; b.xq_refused = false; b.has_xc = false; b.xc_refused = false;
+  b.xp_ksharded = false;
+  {
+    int64_t k0 = 0, kloc = 0;
+    if (want_ksharded_xp(b, K, &k0, &kloc)) {        // this rank's third-mode slab of the SAME tensor, all rows
+      SynthArgs ak = a;
+      ak.I_loc = I; ak.I_pad = pad_of(prec, I); ak.row0 = 0; ak.k0 = k0; ak.K_loc = kloc;
+      DevBuf slab;
+      slab.alloc((size_t)ak.I_pad * J * kloc * b.X.elem_size());
+      synth_write(slab.p, prec, A.d(), B.d(), C.d(), ak, sigma, 1.0 / std::sqrt(nsq), stream_);
+      adopt_ksharded_xp(b, slab.p, k0, kloc);
+      AO_HIP(hipStreamSynchronize(stream_));          // slab is a local
+    }
+  }
   (void)ensure_permuted_copy2(b);                    // set-up cost of the data, like the generation itself
   (void)ensure_blocked_copy(b);
   AO_HIP(hipStreamSynchronize(stream_));
@@ -905,10 +940,32 @@ static int next_update_distance(int pos, int c, const int* seq, int n) {
 // position `pos` (a cached one is reused while its factor is unchanged).
 // Second resident copy with the first mode last (see CpBlock::Xp).  Built lazily; refused when the mask of an EM
 // problem would have to be kept in sync, when the caller opted out, or when HBM cannot hold it.
-static size_t blocked_bytes(int64_t M, int64_t C, size_t es) { return (size_t)round_up(M, kRowBlockElems) * C * es; }
+
 static bool room_for(size_t bytes) {
   size_t free_b = 0, total_b = 0;
   return hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= bytes + (size_t)(4ull << 30);
+}
+
+// Mode-3 sharding of the mode-1 pass's copy: every rank must reach the same verdict (the collectives that follow the
+// pass differ: own rows of mode 3 instead of partial sums).
+bool Engine::want_ksharded_xp(const CpBlock& b, int64_t K, int64_t* k0, int64_t* kloc) const {
+  static const bool off = getenv("AOADMM_NO_KSHARD") != nullptr;            // development switch
+  if (!sharded() || world_ <= 1 || !allow_xp_ || b.has_mask || b.nd != 3 || off) return false;
+  const int64_t per = cdiv(K, world_);
+  if (per * (world_ - 1) >= K) return false;          // some rank would own no slab
+  *k0 = per * rank_;
+  *kloc = std::min<int64_t>(K, *k0 + per) - *k0;
+  return true;
+}
+void Engine::adopt_ksharded_xp(CpBlock& b, const void* slab, int64_t k0, int64_t kloc) {
+  const int64_t Ifull = b.full0, J = b.dims[1];
+  const int prec = b.X.prec;
+  const int64_t Ipf = round_up(Ifull, prec == AOADMM_PREC_F32 ? 4 : 2);
+  const int64_t Jp = round_up(J, prec == AOADMM_PREC_F32 ? 4 : 2);
+  b.Xp.alloc(blocked_bytes(Jp * kloc, Ifull, b.X.elem_size()));
+  b.Jp = Jp;
+  AO_REQUIRE(block_layout_copy(slab, b.Xp.p, 1, prec, Ifull, Ipf, J, kloc, Jp, stream_), "tensor mode too long for the copy kernels");
+  b.has_xp = true; b.xp_ksharded = true; b.xp_k0 = k0; b.xp_kloc = kloc;
 }
 
 bool Engine::ensure_permuted_copy(CpBlock& b) {
@@ -959,7 +1016,7 @@ bool Engine::ensure_blocked_copy(CpBlock& b) {
   return true;
 }
 void Engine::drop_permuted_copies(CpBlock& b) {
-  if (b.has_xp) { b.Xp.release(); b.has_xp = false; b.cached_mode = -1; }
+  if (b.has_xp) { b.Xp.release(); b.has_xp = false; b.xp_ksharded = false; b.cached_mode = -1; }
   if (b.has_xq) { b.Xq.release(); b.has_xq = false; b.cached_mode = -1; }
   if (b.has_xc) { b.Xc.release(); b.has_xc = false; b.cached_mode = -1; }
 }
@@ -1010,8 +1067,10 @@ void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int 
     Fc = facs[0].p + (sharded() ? b.row0 : 0);
     static const bool force_ldskernel = getenv("AOADMM_LEAD_KERNEL") != nullptr;   // development switch
     if (!force_ldskernel && ensure_permuted_copy(b)) {
-      // Xp: rows (j, k), columns i -> the register-streaming contraction
-      pl = blocked_plan(b.Jp * K, I);
+      // Xp: rows (j, k), columns i -> the register-streaming contraction.  With a communicator the copy holds this
+      // rank's slab of mode 3 and ALL of mode 1 (CpBlock::xp_ksharded): a complete T of 1/N the size
+      if (b.xp_ksharded) { pl = blocked_plan(b.Jp * b.xp_kloc, b.full0); Fc = facs[0].p; }
+      else pl = blocked_plan(b.Jp * K, I);
       pl.on_xp = true;
     } else {
       pl = make_lead_plan(J * K, Ip, I, R);
@@ -1085,19 +1144,27 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
     ensure_contraction(b, pos, facs, R, use_cache, update_seq, nseq);
     const int c = b.cached_mode;
     const ContractPlan& pl = b.plan;
+    // the mode-1 pass on a copy sharded along mode 3: T(j, k in K_g, r) is complete; mode 3's output is this rank's rows
+    const bool ksh = sharded && pl.on_xp && b.xp_ksharded;
     // T rows are (a + Apad*bb) with (a, bb) the two uncontracted modes in the order the pass's copy stores them:
     // tensor order on X and Xp, (k, i) on Xq
     int ia = c == 0 ? 1 : 0, ib = c == 2 ? 1 : 2;
     if (pl.on_xq) { ia = 2; ib = 0; }
-    const int64_t ext[3] = {I, J, K};
+    const int64_t ext[3] = {I, J, ksh ? b.xp_kloc : K};
     const int64_t An = ext[ia], Bn = ext[ib];
     const int64_t Apad = pl.on_xq ? b.Kp : (ia == 0 ? Ip : (pl.on_xp ? b.Jp : J));
-    // factor of a mode: the first mode's factor is addressed at this rank's rows
-    auto fac_p = [&](int m) { return m == 0 ? F0 : facs[m].p; };
+    // factor of a mode: the first mode's factor is addressed at this rank's rows (the third mode's too under `ksh`)
+    auto fac_p = [&](int m) { return m == 0 ? F0 : (m == 2 && ksh ? facs[2].p + b.xp_k0 : facs[m].p); };
     auto fac_pT = [&](int m) -> const double* {
       if (!facs[m].pT) return nullptr;
+      if (m == 2 && ksh) return facs[2].pT + b.xp_k0 * R;
       return facs[m].pT + ((m == 0 && sharded) ? b.row0 * R : 0);
     };
+    if (ksh && pos == 2) {                             // own rows of a zeroed buffer; the all-reduce is the all-gather
+      for (int r = 0; r < R; ++r)
+        AO_HIP(hipMemsetAsync(out + ldOut * r, 0, (size_t)K * sizeof(double), stream_));
+      out_local = out + b.xp_k0;
+    }
     if (pos == ia) {
       b.scratch.ensure(reduce_outer_scratch_bytes(An, Bn, R));
       b.ft.ensure(reduce_factor_scratch_bytes(Bn, R));
