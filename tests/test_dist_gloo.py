@@ -1,8 +1,10 @@
 """CPU, world_size 2 over gloo: the N > 1 path's algorithm.
 
 The multi-GPU engine row-shards the tensor's first mode, keeps factor matrices replicated and
-all-reduces each MTTKRP output (csrc/solver.hip block_mttkrp + Engine::allreduce).  Here the same
-partition (`row_block`, product code) and the same collective pattern are run with the oracle as
+all-reduces each MTTKRP output (csrc/solver.hip block_mttkrp + Engine::allreduce); the copy for the
+pass that contracts mode 1 is sharded along mode 3 instead (CpBlock::xp_ksharded), so MTTKRPs of
+modes 2 and 3 come from either partition depending on which pass serves them.  Here the same
+partitions (`row_block`, product code) and the same collective pattern are run with the oracle as
 the per-rank compute: the sharded AO-ADMM must give the same factors as the unsharded one, and every
 rank must hold identical factors (replicated ADMM stays in lock-step).
 """
@@ -36,19 +38,30 @@ def _worker(rank, world, initfile, outdir):
     X = Z['object'][0]
     r0, nloc = pkg.row_block(X.shape[0], world, rank)
     Xloc = X[r0:r0 + nloc]
+    k0, kloc = pkg.row_block(X.shape[2], world, rank)    # the mode-3 slab of the mode-1 pass's copy
+    Xk = X[:, :, k0:k0 + kloc]
 
     calls = {'n': 0}
 
     def sharded_mttkrp(Xfull, U, n):
         assert Xfull is X
         calls['n'] += 1
-        Uloc = [U[0][r0:r0 + nloc]] + list(U[1:])
-        part = OT.mttkrp(Xloc, Uloc, n)
-        if n == 0:                                       # own rows into a zero buffer: all-reduce == all-gather
-            full = np.zeros((X.shape[0], part.shape[1]))
-            full[r0:r0 + nloc] = part
+        if n != 0 and calls['n'] % 2 == 1:               # served by the pass on the mode-3 slab (all of mode 1)
+            Uk = [U[0], U[1], U[2][k0:k0 + kloc]]
+            part = OT.mttkrp(Xk, Uk, n)
+            if n == 2:                                   # own rows of mode 3 into a zero buffer
+                full = np.zeros((X.shape[2], part.shape[1]))
+                full[k0:k0 + kloc] = part
+            else:                                        # mode 2: partial sums over this rank's k
+                full = part
         else:
-            full = part
+            Uloc = [U[0][r0:r0 + nloc]] + list(U[1:])
+            part = OT.mttkrp(Xloc, Uloc, n)
+            if n == 0:                                   # own rows into a zero buffer: all-reduce == all-gather
+                full = np.zeros((X.shape[0], part.shape[1]))
+                full[r0:r0 + nloc] = part
+            else:
+                full = part
         t = torch.from_numpy(np.ascontiguousarray(full))
         dist.all_reduce(t)
         return t.numpy()
