@@ -96,7 +96,7 @@ void ctl_reset(AdmmCtl* ctl, hipStream_t s);
 void chol_only(double* L, const double* B, int R, AdmmCtl* ctl, hipStream_t s);
 
 // B = V diag(w) V' for a symmetric n x n matrix, n <= 64 (cyclic Jacobi, one wave)
-void sym_eig_small(const double* B, int n, double* w, double* V, hipStream_t s);
+void sym_eig_small(const double* B, int n, double* w, double* V, hipStream_t s, const AdmmCtl* ctl = nullptr);
 // BB <- AA \ BB, AA symmetric positive definite q x q (destroyed), BB q x nrhs; failure -> ctl->notpd
 void spd_solve_left(double* AA, int64_t q, double* BB, int nrhs, AdmmCtl* ctl, hipStream_t s);
 // Dense SPD system of order n <= kDenseMaxN: M (n x n, column-major) is overwritten by its Cholesky factor, Minv

@@ -607,65 +607,93 @@ void dense_symv_rows(const double* Minv, const double* rhs, double* out, int K, 
 }
 
 // ---------------------------------------------------------------------------
-// Symmetric eigendecomposition of a small matrix (n <= 64) by cyclic Jacobi, one wave, matrix and
-// eigenvectors in LDS: B = V diag(w) V'.  Used by the Sylvester-type primal updates of the transformed
-// couplings (cmtf_fun_AOADMM.m:707, :1016), where B is the R x R system matrix of one mode.
-__global__ __launch_bounds__(64) void sym_eig_small_k(const double* B, int n, double* w, double* V) {
-  extern __shared__ double sh[];          // A[n*n], Q[n*n]
-  __shared__ double cs[2];
+// Symmetric eigendecomposition of a small matrix (n <= 64) by Jacobi rotations, one wave, matrix and eigenvectors in
+// LDS: B = V diag(w) V'.  Used by the Sylvester-type primal updates of the transformed couplings
+// (cmtf_fun_AOADMM.m:707, :1016) and by the orthonormality prox (project_ortho.m), where B is a Gram matrix.
+// Parallel ordering: a sweep is n-1 (n even) tournament rounds of n/2 DISJOINT pairs; lane p computes the rotation of
+// its pair, then all column rotations of the round are applied at once, then all row rotations (disjoint rotations
+// commute).  A serial cyclic sweep took ~1 us per pair with two barriers each (190 pairs at n = 20); a round here is two
+// wave barriers for n/2 pairs.  Fixed schedule, fixed arithmetic order: deterministic.
+__global__ __launch_bounds__(64) void sym_eig_small_k(const double* B, int n, double* w, double* V, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  extern __shared__ double sh[];          // A[n*n], Q[n*n], cs[2*32], pq[2*32] (as ints)
   __shared__ int done;
   double* A = sh;
   double* Q = sh + n * n;
+  double* cs = Q + n * n;                 // c, s of the pair handled by lane p
+  int* pr = reinterpret_cast<int*>(cs + 64);   // p, q of that pair (-1: idle)
   const int t = threadIdx.x;
   for (int e = t; e < n * n; e += 64) { A[e] = B[e]; Q[e] = (e % n == e / n) ? 1.0 : 0.0; }
   __syncthreads();
+  const int m = (n + 1) & ~1;             // players of the tournament (one dummy when n is odd)
+  const int half = m / 2;
   for (int sweep = 0; sweep < 60; ++sweep) {
-    if (t == 0) {
-      double off = 0.0, tot = 0.0;
-      for (int j = 0; j < n; ++j)
-        for (int i = 0; i < n; ++i) { const double v = A[i + n * j]; tot += v * v; if (i != j) off += v * v; }
-      done = !(off > 1e-30 * tot);
-    }
+    double off = 0.0, tot = 0.0;
+    for (int e = t; e < n * n; e += 64) { const double v = A[e]; tot += v * v; if (e % n != e / n) off += v * v; }
+    for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o); tot += __shfl_xor(tot, o); }
+    if (t == 0) done = !(off > 1e-30 * tot);
     __syncthreads();
     if (done) break;
-    for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        if (t == 0) {
+    for (int r = 0; r < m - 1; ++r) {
+      if (t < half) {
+        // round r of the circle method: player m-1 is fixed, the others rotate
+        int a, b;
+        if (t == 0) { a = m - 1; b = r; }
+        else { a = (r + t) % (m - 1); b = (r - t + (m - 1)) % (m - 1); }
+        int p = a < b ? a : b, q = a < b ? b : a;
+        double c = 1.0, sn = 0.0;
+        if (q < n) {
           const double apq = A[p + n * q];
-          double c = 1.0, s = 0.0;
           if (apq != 0.0) {
             const double theta = (A[q + n * q] - A[p + n * p]) / (2.0 * apq);
             const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
             c = 1.0 / sqrt(tt * tt + 1.0);
-            s = tt * c;
+            sn = tt * c;
           }
-          cs[0] = c; cs[1] = s;
+        } else {
+          p = -1;                          // the pair with the dummy player sits out
         }
-        __syncthreads();
-        const double c = cs[0], s = cs[1];
-        if (s != 0.0 && t < n) {                     // columns p, q of A and of Q (thread = row)
-          const double akp = A[t + n * p], akq = A[t + n * q];
-          A[t + n * p] = c * akp - s * akq;
-          A[t + n * q] = s * akp + c * akq;
-          const double qkp = Q[t + n * p], qkq = Q[t + n * q];
-          Q[t + n * p] = c * qkp - s * qkq;
-          Q[t + n * q] = s * qkp + c * qkq;
-        }
-        __syncthreads();
-        if (s != 0.0 && t < n) {                     // rows p, q of A (thread = column)
-          const double apk = A[p + n * t], aqk = A[q + n * t];
-          A[p + n * t] = c * apk - s * aqk;
-          A[q + n * t] = s * apk + c * aqk;
-        }
-        __syncthreads();
+        cs[2 * t] = c; cs[2 * t + 1] = sn;
+        pr[2 * t] = p; pr[2 * t + 1] = q;
       }
+      __syncthreads();
+      // columns p, q of A and of Q for every pair: element (k, pair)
+      for (int e = t; e < half * n; e += 64) {
+        const int pi = e / n, k = e - pi * n;
+        const int p = pr[2 * pi], q = pr[2 * pi + 1];
+        const double c = cs[2 * pi], sn = cs[2 * pi + 1];
+        if (p >= 0 && sn != 0.0) {
+          const double akp = A[k + n * p], akq = A[k + n * q];
+          A[k + n * p] = c * akp - sn * akq;
+          A[k + n * q] = sn * akp + c * akq;
+          const double qkp = Q[k + n * p], qkq = Q[k + n * q];
+          Q[k + n * p] = c * qkp - sn * qkq;
+          Q[k + n * q] = sn * qkp + c * qkq;
+        }
+      }
+      __syncthreads();
+      // rows p, q of A for every pair: element (pair, k)
+      for (int e = t; e < half * n; e += 64) {
+        const int pi = e / n, k = e - pi * n;
+        const int p = pr[2 * pi], q = pr[2 * pi + 1];
+        const double c = cs[2 * pi], sn = cs[2 * pi + 1];
+        if (p >= 0 && sn != 0.0) {
+          const double apk = A[p + n * k], aqk = A[q + n * k];
+          A[p + n * k] = c * apk - sn * aqk;
+          A[q + n * k] = sn * apk + c * aqk;
+        }
+      }
+      __syncthreads();
+    }
   }
   for (int e = t; e < n * n; e += 64) V[e] = Q[e];
   if (t < n) w[t] = A[t + n * t];
 }
-void sym_eig_small(const double* B, int n, double* w, double* V, hipStream_t s) {
+void sym_eig_small(const double* B, int n, double* w, double* V, hipStream_t s, const AdmmCtl* ctl) {
   AO_REQUIRE(n >= 1 && n <= kMaxRank, "sym_eig_small: n out of range");
-  sym_eig_small_k<<<1, 64, (size_t)2 * n * n * sizeof(double), s>>>(B, n, w, V);
+  const size_t sh = ((size_t)2 * n * n + 64 + 64) * sizeof(double);
+  if (sh > 65536) ensure_dynamic_lds(reinterpret_cast<const void*>(sym_eig_small_k), (int)sh);
+  sym_eig_small_k<<<1, 64, sh, s>>>(B, n, w, V, ctl);
   AO_KERNEL_CHECK();
 }
 
