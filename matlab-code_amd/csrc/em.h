@@ -18,7 +18,7 @@ struct EmCpArgs {
   int R;
   int update;              // 0: statistics only, 1: also overwrite the missing entries
 };
-size_t em_cp_ws_bytes(int64_t Ipad, int64_t K);
+size_t em_cp_ws_bytes(int64_t Ipad, int64_t J, int64_t K);
 // ws: em_cp_ws_bytes ; out4: device, 4 doubles
 void em_cp_pass(const EmCpArgs& a, int prec, double* ws, double* out4, hipStream_t s);
 

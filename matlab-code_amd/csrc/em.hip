@@ -14,8 +14,6 @@ namespace aoadmm {
 template <typename T, int VEC> struct EmVec;
 template <> struct EmVec<float, 4> { typedef float type __attribute__((ext_vector_type(4))); typedef uint32_t mtype; };
 template <> struct EmVec<double, 2> { typedef double type __attribute__((ext_vector_type(2))); typedef uint16_t mtype; };
-template <> struct EmVec<float, 1> { typedef float type; typedef uint8_t mtype; };
-template <> struct EmVec<double, 1> { typedef double type; typedef uint8_t mtype; };
 
 static constexpr int kEmThreads = 256;
 static constexpr int kEmJTile = 64;
@@ -29,92 +27,168 @@ __device__ __forceinline__ double em_block_sum(double v, double* sh4) {
   return r;
 }
 
+// Strip kernel for R <= 32.  Everything in the column loop is branch-free vector arithmetic in the tensor's
+// precision (v_pk_*_f32 for fp32): the first version spent ~330 vector instructions per 16-byte vector of entries
+// (a register ring shifted with moves, one branch per entry, fp64 statistics) and was bound by instruction issue
+// at 4.3 TB/s, not by memory.
+//   * VEC rows of A (times C(k,:)) per thread, held as R vectors areg[r]; B rows broadcast from LDS (ds_read_b128)
+//   * loads run PD columns ahead in a statically indexed register ring (the column loop is unrolled by PD)
+//   * the four statistics are accumulated per 64-column tile in the tensor's precision (64 terms per accumulator
+//     lane) and join the fp64 sums once per tile
+//   * padding rows (i >= I; the tensor holds zeros there) get a zero row of A and are forced 'observed': they add
+//     exact zeros and are written back unchanged
+//   * every vector is written back with a streaming store, not only those with a missing entry: whole cache lines
+//     leave and nothing is read-modified-written in L2
 template <typename T, int VEC, int RMAX>
-__global__ __launch_bounds__(kEmThreads) void em_cp_k(EmCpArgs a, double* ws) {
+__global__ __launch_bounds__(kEmThreads) void em_cp_vec_k(EmCpArgs a, int jchunks, int64_t jlen, double* ws) {
   typedef typename EmVec<T, VEC>::type XV;
   typedef typename EmVec<T, VEC>::mtype MV;
-  __shared__ T Bsh[kEmJTile][RMAX];
+  __shared__ __attribute__((aligned(16))) T Bsh[kEmJTile][RMAX];
   __shared__ double sh4[4];
   const int R = a.R;
   const int t = threadIdx.x;
   const int64_t k = blockIdx.y;
-  const int64_t i0 = ((int64_t)blockIdx.x * kEmThreads + t) * VEC;       // first row of this thread
-  // rows of A scaled by C(k,:): m(i,j,k) = sum_r (A(i,r) C(k,r)) B(j,r)
-  T areg[VEC][RMAX];
+  const int chunk = blockIdx.x % jchunks;                                // the second mode is cut into jchunks pieces
+  const int64_t i0 = ((int64_t)(blockIdx.x / jchunks) * kEmThreads + t) * VEC;   // first row of this thread
+  const int64_t jbeg = chunk * jlen, jend = jbeg + jlen < a.J ? jbeg + jlen : a.J;
+  XV areg[RMAX];                                                         // areg[r][v] = A(i0+v, r) * C(k, r)
+  MV padmask = 0;
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    const int64_t i = i0 + v < a.I ? i0 + v : a.I - 1;                  // clamped: padding rows are skipped below
+  for (int v = 0; v < VEC; ++v)
+    if (i0 + v >= a.I) padmask |= (MV)((MV)0xff << (8 * v));
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-      const int rr = r < R ? r : 0;
-      const double c = a.C ? a.C[k + a.ldC * rr] : 1.0;
-      areg[v][r] = r < R ? (T)(a.A[i + a.ldA * rr] * c) : (T)0;
+  for (int r = 0; r < RMAX; ++r) {
+    const int rr = r < R ? r : 0;
+    const double c = a.C ? a.C[k + a.ldC * rr] : 1.0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const bool valid = i0 + v < a.I;
+      const int64_t i = valid ? i0 + v : a.I - 1;
+      areg[r][v] = (r < R && valid) ? (T)(a.A[i + a.ldA * rr] * c) : (T)0;
     }
   }
   T* X = reinterpret_cast<T*>(a.X) + a.Ipad * a.J * k;
   const uint8_t* M = a.mask + a.Ipad * a.J * k;
   const bool in_range = i0 < a.Ipad;                                     // Ipad is a multiple of VEC
+  const XV zero = {};
   double num = 0, den = 0, ores = 0, ox2 = 0;
-  for (int64_t j0 = 0; j0 < a.J; j0 += kEmJTile) {
+  for (int64_t j0 = jbeg; j0 < jend; j0 += kEmJTile) {
     __syncthreads();
     for (int e = t; e < kEmJTile * RMAX; e += kEmThreads) {
       const int jj = e / RMAX, r = e - jj * RMAX;
-      Bsh[jj][r] = (r < R && j0 + jj < a.J) ? (T)a.B[j0 + jj + a.ldB * r] : (T)0;
+      Bsh[jj][r] = (r < R && j0 + jj < jend) ? (T)a.B[j0 + jj + a.ldB * r] : (T)0;
     }
     __syncthreads();
-    const int nj = (int)((a.J - j0 < kEmJTile) ? (a.J - j0) : kEmJTile);
+    const int nj = (int)((jend - j0 < kEmJTile) ? (jend - j0) : kEmJTile);
     if (!in_range) continue;
-    // the loads run PD columns ahead of the arithmetic (register ring): with one 16-byte load and its
-    // mask word per iteration and ~100 FMAs behind them, nothing else hides the memory latency at 4 waves per SIMD
     constexpr int PD = 4;                              // columns in flight
     XV xq[PD]; MV mq[PD];
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
       const int64_t op = i0 + a.Ipad * (j0 + (p < nj ? p : nj - 1));
-      xq[p] = *reinterpret_cast<const XV*>(X + op);
-      mq[p] = *reinterpret_cast<const MV*>(M + op);
+      xq[p] = __builtin_nontemporal_load(reinterpret_cast<const XV*>(X + op));
+      mq[p] = __builtin_nontemporal_load(reinterpret_cast<const MV*>(M + op));
     }
-    for (int jj = 0; jj < nj; ++jj) {
-      const int64_t o = i0 + a.Ipad * (j0 + jj);
-      XV xv = xq[0];
-      const MV mv = mq[0];
+    XV s_ores = zero, s_ox2 = zero, s_num = zero, s_den = zero;
+    for (int jj = 0; jj < nj; jj += PD) {
 #pragma unroll
-      for (int p = 0; p + 1 < PD; ++p) { xq[p] = xq[p + 1]; mq[p] = mq[p + 1]; }
-      {
-        const int jn = jj + PD < nj ? jj + PD : nj - 1;                  // clamped: the last loads are discarded
-        const int64_t on = i0 + a.Ipad * (j0 + jn);
-        xq[PD - 1] = *reinterpret_cast<const XV*>(X + on);
-        mq[PD - 1] = *reinterpret_cast<const MV*>(M + on);
-      }
-      T m[VEC];
+      for (int p = 0; p < PD; ++p) {
+        const int jc = jj + p;                                           // wave-uniform
+        const XV xv = xq[p];
+        const MV mv = mq[p] | padmask;
+        {
+          const int jn = jc + PD < nj ? jc + PD : nj - 1;                // clamped: the last loads are discarded
+          const int64_t on = i0 + a.Ipad * (j0 + jn);
+          xq[p] = __builtin_nontemporal_load(reinterpret_cast<const XV*>(X + on));
+          mq[p] = __builtin_nontemporal_load(reinterpret_cast<const MV*>(M + on));
+        }
+        if (jc < nj) {
+          XV m = zero;
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) m[v] = (T)0;
+          for (int r = 0; r < RMAX; ++r) {
+            const T b = Bsh[jc][r];
+            XV bb;
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) {
-        const T b = Bsh[jj][r];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) m[v] += areg[v][r] * b;
-      }
-      bool any_missing = false;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        if (i0 + v < a.I) {
-          T x;
-          if constexpr (VEC == 1) x = xv; else x = xv[v];
-          const bool observed = ((mv >> (8 * v)) & 0xff) != 0;
-          const double xd = (double)x, md = (double)m[v];
-          if (observed) {
-            ores += (xd - md) * (xd - md);
-            ox2 += xd * xd;
-          } else {
-            num += (md - xd) * (md - xd);
-            den += xd * xd;
-            if constexpr (VEC == 1) xv = m[v]; else xv[v] = m[v];
-            any_missing = true;
+            for (int v = 0; v < VEC; ++v) bb[v] = b;
+            m = __builtin_elementwise_fma(areg[r], bb, m);
           }
+          const XV d = xv - m;
+          XV od, ox, xn;                                                 // residual / value where observed, else 0
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const bool observed = ((mv >> (8 * v)) & 0xff) != 0;
+            od[v] = observed ? d[v] : (T)0;
+            ox[v] = observed ? xv[v] : (T)0;
+            xn[v] = observed ? xv[v] : m[v];
+          }
+          const XV md = d - od, mx = xv - ox;                            // the same where missing (exact)
+          s_ores = __builtin_elementwise_fma(od, od, s_ores);
+          s_ox2 = __builtin_elementwise_fma(ox, ox, s_ox2);
+          s_num = __builtin_elementwise_fma(md, md, s_num);
+          s_den = __builtin_elementwise_fma(mx, mx, s_den);
+          if (a.update) __builtin_nontemporal_store(xn, reinterpret_cast<XV*>(X + i0 + a.Ipad * (j0 + jc)));
         }
       }
-      if (a.update && any_missing) *reinterpret_cast<XV*>(X + o) = xv;
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      ores += (double)s_ores[v]; ox2 += (double)s_ox2[v]; num += (double)s_num[v]; den += (double)s_den[v];
+    }
+  }
+  num = em_block_sum(num, sh4); den = em_block_sum(den, sh4);
+  ores = em_block_sum(ores, sh4); ox2 = em_block_sum(ox2, sh4);
+  if (t == 0) {
+    double* w = ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+    w[0] = num; w[1] = den; w[2] = ores; w[3] = ox2;
+  }
+}
+
+// One row per thread, for R > 32 (the rows of A no longer fit in registers VEC at a time).
+template <typename T, int RMAX>
+__global__ __launch_bounds__(kEmThreads) void em_cp_k(EmCpArgs a, int jchunks, int64_t jlen, double* ws) {
+  __shared__ T Bsh[kEmJTile][RMAX];
+  __shared__ double sh4[4];
+  const int R = a.R;
+  const int t = threadIdx.x;
+  const int64_t k = blockIdx.y;
+  const int chunk = blockIdx.x % jchunks;
+  const int64_t i0 = (int64_t)(blockIdx.x / jchunks) * kEmThreads + t;
+  const int64_t jbeg = chunk * jlen, jend = jbeg + jlen < a.J ? jbeg + jlen : a.J;
+  T areg[RMAX];
+  {
+    const int64_t i = i0 < a.I ? i0 : a.I - 1;                          // clamped: padding rows are skipped below
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const int rr = r < R ? r : 0;
+      const double c = a.C ? a.C[k + a.ldC * rr] : 1.0;
+      areg[r] = r < R ? (T)(a.A[i + a.ldA * rr] * c) : (T)0;
+    }
+  }
+  T* X = reinterpret_cast<T*>(a.X) + a.Ipad * a.J * k;
+  const uint8_t* M = a.mask + a.Ipad * a.J * k;
+  double num = 0, den = 0, ores = 0, ox2 = 0;
+  for (int64_t j0 = jbeg; j0 < jend; j0 += kEmJTile) {
+    __syncthreads();
+    for (int e = t; e < kEmJTile * RMAX; e += kEmThreads) {
+      const int jj = e / RMAX, r = e - jj * RMAX;
+      Bsh[jj][r] = (r < R && j0 + jj < jend) ? (T)a.B[j0 + jj + a.ldB * r] : (T)0;
+    }
+    __syncthreads();
+    const int nj = (int)((jend - j0 < kEmJTile) ? (jend - j0) : kEmJTile);
+    if (i0 >= a.I) continue;
+    for (int jj = 0; jj < nj; ++jj) {
+      const int64_t o = i0 + a.Ipad * (j0 + jj);
+      const T x = X[o];
+      T m = (T)0;
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) m += areg[r] * Bsh[jj][r];
+      const T d = x - m;
+      if (M[o]) {
+        ores += (double)(d * d); ox2 += (double)(x * x);
+      } else {
+        num += (double)(d * d); den += (double)(x * x);
+        if (a.update) X[o] = m;
+      }
     }
   }
   num = em_block_sum(num, sh4); den = em_block_sum(den, sh4);
@@ -140,16 +214,37 @@ __global__ __launch_bounds__(256) void em_sum4_k(const double* ws, int64_t nb, d
   }
 }
 
-size_t em_cp_ws_bytes(int64_t Ipad, int64_t K) {
-  return (size_t)(cdiv(Ipad, kEmThreads) * K) * 4 * sizeof(double);   // VEC >= 1: never more strips than this
+// The second mode is cut into pieces of whole 64-column tiles so that the launch has several thousand workgroups:
+// with one workgroup per (strip, k) a 1000^3 block gave 1000 workgroups for 768 resident slots -- a second round on a
+// third of the chip, each CU with too few loads in flight -- and a matrix block gave one workgroup per strip.
+static constexpr int64_t kEmTargetBlocks = 6144;
+static void em_chunking(int64_t strips, int64_t J, int64_t K, int* jchunks, int64_t* jlen) {
+  const int64_t tiles = cdiv(J, (int64_t)kEmJTile);
+  int64_t want = cdiv(kEmTargetBlocks, strips * K);
+  if (want > tiles) want = tiles;
+  if (want < 1) want = 1;
+  *jlen = cdiv(tiles, want) * kEmJTile;
+  *jchunks = (int)cdiv(J, *jlen);
+}
+
+size_t em_cp_ws_bytes(int64_t Ipad, int64_t J, int64_t K) {
+  // strips <= cdiv(Ipad, 256) (VEC >= 1) and pieces <= cdiv(kEmTargetBlocks, strips * K): never more workgroups than this
+  (void)J;
+  return (size_t)(cdiv(Ipad, (int64_t)kEmThreads) * K + kEmTargetBlocks) * 4 * sizeof(double);
 }
 
 template <typename T, int VEC>
-static void em_cp_launch(const EmCpArgs& a, double* ws, dim3 grid, hipStream_t s) {
-  if (a.R <= 8) em_cp_k<T, VEC, 8><<<grid, kEmThreads, 0, s>>>(a, ws);
-  else if (a.R <= 16) em_cp_k<T, VEC, 16><<<grid, kEmThreads, 0, s>>>(a, ws);
-  else if (a.R <= 24) em_cp_k<T, VEC, 24><<<grid, kEmThreads, 0, s>>>(a, ws);
-  else em_cp_k<T, VEC, 32><<<grid, kEmThreads, 0, s>>>(a, ws);
+static void em_cp_launch(const EmCpArgs& a, int jchunks, int64_t jlen, double* ws, dim3 grid, hipStream_t s) {
+  switch ((a.R + 3) / 4) {                           // rank rounded up to a multiple of 4 (one ds_read_b128 of fp32)
+    case 1: em_cp_vec_k<T, VEC, 4><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    case 2: em_cp_vec_k<T, VEC, 8><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    case 3: em_cp_vec_k<T, VEC, 12><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    case 4: em_cp_vec_k<T, VEC, 16><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    case 5: em_cp_vec_k<T, VEC, 20><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    case 6: em_cp_vec_k<T, VEC, 24><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    case 7: em_cp_vec_k<T, VEC, 28><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    default: em_cp_vec_k<T, VEC, 32><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+  }
 }
 
 void em_cp_pass(const EmCpArgs& a, int prec, double* ws, double* out4, hipStream_t s) {
@@ -157,13 +252,17 @@ void em_cp_pass(const EmCpArgs& a, int prec, double* ws, double* out4, hipStream
   AO_REQUIRE(a.K <= 65535, "em_cp_pass: third mode too long for one launch");
   const bool wide = a.R <= 32;                       // VEC rows of A in registers; beyond 32 columns one row per thread
   const int vec = !wide ? 1 : (prec == AOADMM_PREC_F32 ? 4 : 2);
-  const dim3 grid((unsigned)cdiv(a.Ipad, (int64_t)kEmThreads * vec), (unsigned)a.K);
+  const int64_t strips = cdiv(a.Ipad, (int64_t)kEmThreads * vec);
+  int jchunks; int64_t jlen;
+  em_chunking(strips, a.J, a.K, &jchunks, &jlen);
+  const dim3 grid((unsigned)(strips * jchunks), (unsigned)a.K);
+  AO_REQUIRE((size_t)grid.x * grid.y * 4 * sizeof(double) <= em_cp_ws_bytes(a.Ipad, a.J, a.K), "em_cp_pass: workspace");
   if (prec == AOADMM_PREC_F32) {
-    if (wide) em_cp_launch<float, 4>(a, ws, grid, s);
-    else em_cp_k<float, 1, 64><<<grid, kEmThreads, 0, s>>>(a, ws);
+    if (wide) em_cp_launch<float, 4>(a, jchunks, jlen, ws, grid, s);
+    else em_cp_k<float, 64><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws);
   } else {
-    if (wide) em_cp_launch<double, 2>(a, ws, grid, s);
-    else em_cp_k<double, 1, 64><<<grid, kEmThreads, 0, s>>>(a, ws);
+    if (wide) em_cp_launch<double, 2>(a, jchunks, jlen, ws, grid, s);
+    else em_cp_k<double, 64><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws);
   }
   AO_KERNEL_CHECK();
   em_sum4_k<<<1, 256, 0, s>>>(ws, (int64_t)grid.x * grid.y, out4);

@@ -747,7 +747,7 @@ void Engine::em_pass_enqueue(int p, int update) {
     }
     a.C = cur; a.ldC = curK; a.K = curK;
   }
-  emws_.ensure(em_cp_ws_bytes(a.Ipad, a.K));
+  emws_.ensure(em_cp_ws_bytes(a.Ipad, a.J, a.K));
   em_cp_pass(a, b.X.prec, emws_.d(), em_slot(p), stream_);
   if (b.nd == 2 && update) {
     // same imputation on the transposed copy (roles of the two factors swapped); its statistics are discarded
@@ -755,7 +755,7 @@ void Engine::em_pass_enqueue(int p, int update) {
     at.X = b.Xt.data.p; at.mask = b.maskT.as<uint8_t>();
     at.A = m1.fac.d(); at.ldA = m1.rows; at.B = m0.fac.d() + (sharded() ? b.row0 : 0); at.ldB = m0.rows;
     at.I = b.dims[1]; at.Ipad = b.Xt.pad0; at.J = b.dims[0];
-    const size_t wsb = em_cp_ws_bytes(at.Ipad, 1);
+    const size_t wsb = em_cp_ws_bytes(at.Ipad, at.J, 1);
     emws_.ensure(wsb + 64);
     em_cp_pass(at, b.Xt.prec, emws_.d(), emws_.d() + wsb / sizeof(double), stream_);   // statistics to a scratch tail
   }

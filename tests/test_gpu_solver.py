@@ -270,6 +270,21 @@ def test_em_missing_fp32_tensor(pkg, eng):
     assert np.allclose(og['func_rel_missing'][1:], oo['func_rel_missing'][1:], rtol=1e-3)
 
 
+@pytest.mark.parametrize('dims,R,prec', [((70, 200, 30), 5, 'f64'), ((70, 200, 30), 5, 'f32'),
+                                         ((9, 400, 500), 20, 'f32'), ((130, 300), 7, 'f64')])
+def test_em_missing_column_pieces(pkg, eng, dims, R, prec):
+    """The EM pass cuts the second mode into pieces of whole 64-column tiles (em.hip: em_chunking): several pieces per
+    slab with a short last one, several tiles per piece, a ragged first mode, ranks in different register classes."""
+    rng = np.random.default_rng(35)
+    Z, io, _ = cp_model(dims, R, rng, [('non-negativity',)] + [None] * (len(dims) - 1))
+    Z = _with_mask(Z, rng)
+    Fo, oo, Fg, og = run_both(pkg, eng, Z, io, options(MaxOuterIters=4), precision=prec)
+    tol = 1e-4 if prec == 'f32' else 1e-8
+    for a, b in zip(Fo['fac'], Fg['fac']):
+        assert rel_fro(b, a) < tol
+    assert np.allclose(og['func_rel_missing'][1:], oo['func_rel_missing'][1:], rtol=1e-3 if prec == 'f32' else 1e-7)
+
+
 @pytest.mark.parametrize('cB', [('GL smoothness', 1.0), ('TV regularization', 0.01), ('l1 regularization', 0.01),
                                 ('ridge', 0.1), ('l2 regularization', 0.05)])
 def test_parafac2_regularised_Bk(pkg, eng, cB):
