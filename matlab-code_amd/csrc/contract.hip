@@ -750,7 +750,6 @@ void launch_contract(const void* X, int prec, const ContractPlan& pl, const doub
     return;
   }
   const int64_t Cg = cdiv(pl.C, kGroup);
-  const int NT = nt_of(pl.R, prec);
   KArgs a;
   a.X = X; a.frag = frag_ws; a.T = T;
   a.tiles_per_batch = cdiv(pl.M, tile_rows(prec));

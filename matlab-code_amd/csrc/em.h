@@ -17,7 +17,18 @@ struct EmCpArgs {
   int64_t I, Ipad, J, K;   // local rows, padded rows, second mode, third mode (1 for matrices)
   int R;
   int update;              // 0: statistics only, 1: also overwrite the missing entries
+  // 1 (default): a workgroup walks the second mode at a fixed third-mode index; 2: it walks the third mode at a
+  // fixed second-mode index (3-way blocks only)
+  int walk = 1;
+  // Fused tensor pass (null: none).  T[chunk][i + Ipad*f][r] = sum over the chunk's part of the walked mode of
+  // x_new(i, w, f) * W(w, r), in the tensor's precision: what launch_contract would leave for a plan that contracts the
+  // walked mode (ContractPlan in contract.h; chunks = em_cp_fused_chunks, t_chunk_stride = rows of T times R).
+  void* T = nullptr;
+  int64_t t_chunk_stride = 0;
 };
+constexpr int kEmFuseMaxRank = 24;
+bool em_cp_can_fuse(const EmCpArgs& a, int prec);
+int em_cp_fused_chunks(const EmCpArgs& a, int prec);
 size_t em_cp_ws_bytes(int64_t Ipad, int64_t J, int64_t K);
 // ws: em_cp_ws_bytes ; out4: device, 4 doubles
 void em_cp_pass(const EmCpArgs& a, int prec, double* ws, double* out4, hipStream_t s);

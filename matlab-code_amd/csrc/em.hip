@@ -9,6 +9,8 @@
 // the pass is bound by HBM like the contractions.
 #include "em.h"
 
+#include <type_traits>
+
 namespace aoadmm {
 
 template <typename T, int VEC> struct EmVec;
@@ -27,6 +29,71 @@ __device__ __forceinline__ double em_block_sum(double v, double* sh4) {
   return r;
 }
 
+// acc + a * b[h] on both rows of a register pair: v_pk_fma_f32 reading one half of the pair `b` for both lanes
+// (op_sel), so a broadcast LDS value needs no copy into a second register -- the compiler's form of `a * splat(b)` spent
+// a v_mov and a register per rank column on it.
+typedef float em_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ em_f2 pk_fma_lo(em_f2 a, em_f2 b, em_f2 acc) {
+  em_f2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+  return d;
+}
+__device__ __forceinline__ em_f2 pk_fma_hi(em_f2 a, em_f2 b, em_f2 acc) {
+  em_f2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+  return d;
+}
+
+// m + sum_r areg[r] * brow[r]   (brow: one row of the LDS tile, the same for every lane)
+template <typename T, int VEC, int RMAX, typename XV>
+__device__ __forceinline__ XV em_row_dot(const XV* areg, const T* brow, XV m) {
+  if constexpr (std::is_same<T, float>::value && VEC == 4) {
+    em_f2 m01 = m.xy, m23 = m.zw;
+#pragma unroll
+    for (int r = 0; r < RMAX; r += 2) {
+      const em_f2 b2 = *reinterpret_cast<const em_f2*>(brow + r);
+      m01 = pk_fma_lo(areg[r].xy, b2, m01); m23 = pk_fma_lo(areg[r].zw, b2, m23);
+      m01 = pk_fma_hi(areg[r + 1].xy, b2, m01); m23 = pk_fma_hi(areg[r + 1].zw, b2, m23);
+    }
+    XV o;
+    o.xy = m01; o.zw = m23;
+    return o;
+  } else {
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const T b = brow[r];
+      XV bb;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) bb[v] = b;
+      m = __builtin_elementwise_fma(areg[r], bb, m);
+    }
+    return m;
+  }
+}
+
+// tacc[r] += x * brow[r]
+template <typename T, int VEC, int RMAX, typename XV>
+__device__ __forceinline__ void em_row_axpy(XV* tacc, const T* brow, XV x) {
+  if constexpr (std::is_same<T, float>::value && VEC == 4) {
+    const em_f2 x01 = x.xy, x23 = x.zw;
+#pragma unroll
+    for (int r = 0; r < RMAX; r += 2) {
+      const em_f2 b2 = *reinterpret_cast<const em_f2*>(brow + r);
+      tacc[r].xy = pk_fma_lo(x01, b2, tacc[r].xy); tacc[r].zw = pk_fma_lo(x23, b2, tacc[r].zw);
+      tacc[r + 1].xy = pk_fma_hi(x01, b2, tacc[r + 1].xy); tacc[r + 1].zw = pk_fma_hi(x23, b2, tacc[r + 1].zw);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const T b = brow[r];
+      XV bb;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) bb[v] = b;
+      tacc[r] = __builtin_elementwise_fma(x, bb, tacc[r]);
+    }
+  }
+}
+
 // Strip kernel for R <= 32.  Everything in the column loop is branch-free vector arithmetic in the tensor's
 // precision (v_pk_*_f32 for fp32): the first version spent ~330 vector instructions per 16-byte vector of entries
 // (a register ring shifted with moves, one branch per entry, fp64 statistics) and was bound by instruction issue
@@ -39,19 +106,31 @@ __device__ __forceinline__ double em_block_sum(double v, double* sh4) {
 //     exact zeros and are written back unchanged
 //   * every vector is written back with a streaming store, not only those with a missing entry: whole cache lines
 //     leave and nothing is read-modified-written in L2
-template <typename T, int VEC, int RMAX>
-__global__ __launch_bounds__(kEmThreads) void em_cp_vec_k(EmCpArgs a, int jchunks, int64_t jlen, double* ws) {
+//   * the strip can walk the second mode at a fixed third-mode index (walk = 1) or the third mode at a fixed
+//     second-mode index (walk = 2, steps of Ipad*J elements); with FUSE it also accumulates, from the values it
+//     writes back, the partial contraction of the walked mode  T(i, f, r) = sum_w x_new(i, w, f) W(w, r)  -- the
+//     tensor pass the next outer iteration would start with (contract.h ContractPlan: T is [chunk][i + Ipad*f][R]
+//     in the tensor's precision, one chunk per piece of the walk)
+template <typename T, int VEC, int RMAX, bool FUSE>
+__global__ __launch_bounds__(kEmThreads, FUSE ? 2 : 1) void em_cp_vec_k(EmCpArgs a, int jchunks, int64_t jlen, double* ws) {
   typedef typename EmVec<T, VEC>::type XV;
   typedef typename EmVec<T, VEC>::mtype MV;
   __shared__ __attribute__((aligned(16))) T Bsh[kEmJTile][RMAX];
   __shared__ double sh4[4];
   const int R = a.R;
   const int t = threadIdx.x;
-  const int64_t k = blockIdx.y;
-  const int chunk = blockIdx.x % jchunks;                                // the second mode is cut into jchunks pieces
+  const bool wj = a.walk != 2;                                           // walking the second mode
+  const int64_t f = blockIdx.y;                                          // the fixed index (k, or j when walking k)
+  const int64_t NW = wj ? a.J : a.K;
+  const double* Ff = wj ? a.C : a.B;                                     // factor of the fixed mode: scales the rows of A
+  const int64_t ldf = wj ? a.ldC : a.ldB;
+  const double* Fw = wj ? a.B : a.C;                                     // factor of the walked mode: rows through LDS
+  const int64_t ldw = wj ? a.ldB : a.ldC;
+  const int64_t step = wj ? a.Ipad : a.Ipad * a.J;                       // elements between two walk positions
+  const int chunk = blockIdx.x % jchunks;                                // the walk is cut into jchunks pieces
   const int64_t i0 = ((int64_t)(blockIdx.x / jchunks) * kEmThreads + t) * VEC;   // first row of this thread
-  const int64_t jbeg = chunk * jlen, jend = jbeg + jlen < a.J ? jbeg + jlen : a.J;
-  XV areg[RMAX];                                                         // areg[r][v] = A(i0+v, r) * C(k, r)
+  const int64_t jbeg = chunk * jlen, jend = jbeg + jlen < NW ? jbeg + jlen : NW;
+  XV areg[RMAX];                                                         // areg[r][v] = A(i0+v, r) * Ff(f, r)
   MV padmask = 0;
 #pragma unroll
   for (int v = 0; v < VEC; ++v)
@@ -59,24 +138,30 @@ __global__ __launch_bounds__(kEmThreads) void em_cp_vec_k(EmCpArgs a, int jchunk
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) {
     const int rr = r < R ? r : 0;
-    const double c = a.C ? a.C[k + a.ldC * rr] : 1.0;
+    const double c = Ff ? Ff[f + ldf * rr] : 1.0;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const bool valid = i0 + v < a.I;
       const int64_t i = valid ? i0 + v : a.I - 1;
       areg[r][v] = (r < R && valid) ? (T)(a.A[i + a.ldA * rr] * c) : (T)0;
     }
+    // the fp64 loads of this prologue must not all be in flight at once: 2 * VEC * RMAX registers on top of tacc
+    if constexpr (FUSE) { if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
   }
-  T* X = reinterpret_cast<T*>(a.X) + a.Ipad * a.J * k;
-  const uint8_t* M = a.mask + a.Ipad * a.J * k;
+  const int64_t base = (wj ? a.Ipad * a.J : a.Ipad) * f;
+  T* X = reinterpret_cast<T*>(a.X) + base;
+  const uint8_t* M = a.mask + base;
   const bool in_range = i0 < a.Ipad;                                     // Ipad is a multiple of VEC
   const XV zero = {};
+  XV tacc[FUSE ? RMAX : 1];
+#pragma unroll
+  for (int r = 0; r < (FUSE ? RMAX : 1); ++r) tacc[r] = zero;
   double num = 0, den = 0, ores = 0, ox2 = 0;
   for (int64_t j0 = jbeg; j0 < jend; j0 += kEmJTile) {
     __syncthreads();
     for (int e = t; e < kEmJTile * RMAX; e += kEmThreads) {
       const int jj = e / RMAX, r = e - jj * RMAX;
-      Bsh[jj][r] = (r < R && j0 + jj < jend) ? (T)a.B[j0 + jj + a.ldB * r] : (T)0;
+      Bsh[jj][r] = (r < R && j0 + jj < jend) ? (T)Fw[j0 + jj + ldw * r] : (T)0;
     }
     __syncthreads();
     const int nj = (int)((jend - j0 < kEmJTile) ? (jend - j0) : kEmJTile);
@@ -85,7 +170,7 @@ __global__ __launch_bounds__(kEmThreads) void em_cp_vec_k(EmCpArgs a, int jchunk
     XV xq[PD]; MV mq[PD];
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
-      const int64_t op = i0 + a.Ipad * (j0 + (p < nj ? p : nj - 1));
+      const int64_t op = i0 + step * (j0 + (p < nj ? p : nj - 1));
       xq[p] = __builtin_nontemporal_load(reinterpret_cast<const XV*>(X + op));
       mq[p] = __builtin_nontemporal_load(reinterpret_cast<const MV*>(M + op));
     }
@@ -98,20 +183,12 @@ __global__ __launch_bounds__(kEmThreads) void em_cp_vec_k(EmCpArgs a, int jchunk
         const MV mv = mq[p] | padmask;
         {
           const int jn = jc + PD < nj ? jc + PD : nj - 1;                // clamped: the last loads are discarded
-          const int64_t on = i0 + a.Ipad * (j0 + jn);
+          const int64_t on = i0 + step * (j0 + jn);
           xq[p] = __builtin_nontemporal_load(reinterpret_cast<const XV*>(X + on));
           mq[p] = __builtin_nontemporal_load(reinterpret_cast<const MV*>(M + on));
         }
         if (jc < nj) {
-          XV m = zero;
-#pragma unroll
-          for (int r = 0; r < RMAX; ++r) {
-            const T b = Bsh[jc][r];
-            XV bb;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) bb[v] = b;
-            m = __builtin_elementwise_fma(areg[r], bb, m);
-          }
+          const XV m = em_row_dot<T, VEC, RMAX, XV>(areg, &Bsh[jc][0], zero);
           const XV d = xv - m;
           XV od, ox, xn;                                                 // residual / value where observed, else 0
 #pragma unroll
@@ -126,13 +203,41 @@ __global__ __launch_bounds__(kEmThreads) void em_cp_vec_k(EmCpArgs a, int jchunk
           s_ox2 = __builtin_elementwise_fma(ox, ox, s_ox2);
           s_num = __builtin_elementwise_fma(md, md, s_num);
           s_den = __builtin_elementwise_fma(mx, mx, s_den);
-          if (a.update) __builtin_nontemporal_store(xn, reinterpret_cast<XV*>(X + i0 + a.Ipad * (j0 + jc)));
+          if (a.update) __builtin_nontemporal_store(xn, reinterpret_cast<XV*>(X + i0 + step * (j0 + jc)));
+          if constexpr (FUSE) em_row_axpy<T, VEC, RMAX, XV>(tacc, &Bsh[jc][0], xn);
         }
+        // 2 * RMAX vectors are live across the loop: keep the scheduler from interleaving the columns of one
+        // unrolled group (it held four columns' temporaries at once and spilled at R = 20)
+        if constexpr (FUSE) __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       ores += (double)s_ores[v]; ox2 += (double)s_ox2[v]; num += (double)s_num[v]; den += (double)s_den[v];
+    }
+  }
+  if constexpr (FUSE) {
+    if (in_range) {
+      // rows i0 .. i0+VEC-1 of T at fixed index f: VEC*R contiguous values per thread, consecutive threads adjacent
+      T* Tt = reinterpret_cast<T*>(a.T) + (int64_t)chunk * a.t_chunk_stride + (i0 + a.Ipad * f) * R;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if (R == RMAX && (RMAX * sizeof(T)) % 16 == 0) {
+          constexpr int W = 16 / sizeof(T);
+          typedef T TV __attribute__((ext_vector_type(W)));
+#pragma unroll
+          for (int r = 0; r < RMAX; r += W) {
+            TV o;
+#pragma unroll
+            for (int q = 0; q < W; ++q) o[q] = tacc[r + q][v];
+            *reinterpret_cast<TV*>(Tt + (int64_t)v * R + r) = o;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r)
+            if (r < R) Tt[(int64_t)v * R + r] = tacc[r][v];
+        }
+      }
     }
   }
   num = em_block_sum(num, sh4); den = em_block_sum(den, sh4);
@@ -214,54 +319,82 @@ __global__ __launch_bounds__(256) void em_sum4_k(const double* ws, int64_t nb, d
   }
 }
 
-// The second mode is cut into pieces of whole 64-column tiles so that the launch has several thousand workgroups:
-// with one workgroup per (strip, k) a 1000^3 block gave 1000 workgroups for 768 resident slots -- a second round on a
-// third of the chip, each CU with too few loads in flight -- and a matrix block gave one workgroup per strip.
+// The walk is cut into pieces of whole 64-column tiles so that the launch has several thousand workgroups:
+// with one workgroup per (strip, k) a matrix block would be one workgroup per strip.  A fused pass writes one chunk of T per
+// piece, so it only cuts when the launch would not fill the chip, and never runs a piece past the contraction kernels'
+// bound of 2048 terms accumulated in fp32.
 static constexpr int64_t kEmTargetBlocks = 6144;
-static void em_chunking(int64_t strips, int64_t J, int64_t K, int* jchunks, int64_t* jlen) {
-  const int64_t tiles = cdiv(J, (int64_t)kEmJTile);
-  int64_t want = cdiv(kEmTargetBlocks, strips * K);
+static constexpr int64_t kEmFuseBlocks = 768;
+static constexpr int64_t kEmFuseMaxRun = 2048;
+static void em_chunking(int64_t strips, int64_t NW, int64_t NF, bool fuse, int* jchunks, int64_t* jlen) {
+  const int64_t tiles = cdiv(NW, (int64_t)kEmJTile);
+  int64_t want = cdiv(fuse ? kEmFuseBlocks : kEmTargetBlocks, strips * NF);
+  if (fuse && want < cdiv(NW, kEmFuseMaxRun)) want = cdiv(NW, kEmFuseMaxRun);
   if (want > tiles) want = tiles;
   if (want < 1) want = 1;
   *jlen = cdiv(tiles, want) * kEmJTile;
-  *jchunks = (int)cdiv(J, *jlen);
+  *jchunks = (int)cdiv(NW, *jlen);
+}
+
+static bool em_wide(const EmCpArgs& a) { return a.R <= 32; }
+static int em_vec(const EmCpArgs& a, int prec) { return !em_wide(a) ? 1 : (prec == AOADMM_PREC_F32 ? 4 : 2); }
+
+bool em_cp_can_fuse(const EmCpArgs& a, int prec) {
+  (void)prec;
+  return a.R <= kEmFuseMaxRank && a.C != nullptr;    // 2 * R vectors of registers per thread (rows of A and of T)
+}
+
+int em_cp_fused_chunks(const EmCpArgs& a, int prec) {
+  const bool wj = a.walk != 2;
+  int jchunks; int64_t jlen;
+  em_chunking(cdiv(a.Ipad, (int64_t)kEmThreads * em_vec(a, prec)), wj ? a.J : a.K, wj ? a.K : a.J, true, &jchunks, &jlen);
+  return jchunks;
 }
 
 size_t em_cp_ws_bytes(int64_t Ipad, int64_t J, int64_t K) {
-  // strips <= cdiv(Ipad, 256) (VEC >= 1) and pieces <= cdiv(kEmTargetBlocks, strips * K): never more workgroups than this
-  (void)J;
-  return (size_t)(cdiv(Ipad, (int64_t)kEmThreads) * K + kEmTargetBlocks) * 4 * sizeof(double);
+  // strips <= cdiv(Ipad, 256) (VEC >= 1), the fixed index runs over J or K, pieces <= cdiv(kEmTargetBlocks, strips * fixed):
+  // never more workgroups than this
+  return (size_t)(cdiv(Ipad, (int64_t)kEmThreads) * (J > K ? J : K) + kEmTargetBlocks) * 4 * sizeof(double);
 }
 
-template <typename T, int VEC>
+template <typename T, int VEC, bool FUSE>
 static void em_cp_launch(const EmCpArgs& a, int jchunks, int64_t jlen, double* ws, dim3 grid, hipStream_t s) {
   switch ((a.R + 3) / 4) {                           // rank rounded up to a multiple of 4 (one ds_read_b128 of fp32)
-    case 1: em_cp_vec_k<T, VEC, 4><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
-    case 2: em_cp_vec_k<T, VEC, 8><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
-    case 3: em_cp_vec_k<T, VEC, 12><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
-    case 4: em_cp_vec_k<T, VEC, 16><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
-    case 5: em_cp_vec_k<T, VEC, 20><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
-    case 6: em_cp_vec_k<T, VEC, 24><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
-    case 7: em_cp_vec_k<T, VEC, 28><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
-    default: em_cp_vec_k<T, VEC, 32><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    case 1: em_cp_vec_k<T, VEC, 4, FUSE><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    case 2: em_cp_vec_k<T, VEC, 8, FUSE><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    case 3: em_cp_vec_k<T, VEC, 12, FUSE><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    case 4: em_cp_vec_k<T, VEC, 16, FUSE><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    case 5: em_cp_vec_k<T, VEC, 20, FUSE><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    case 6: em_cp_vec_k<T, VEC, 24, FUSE><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws); break;
+    default:
+      if constexpr (!FUSE) {
+        if ((a.R + 3) / 4 == 7) em_cp_vec_k<T, VEC, 28, false><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws);
+        else em_cp_vec_k<T, VEC, 32, false><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws);
+      }
+      break;
   }
 }
 
 void em_cp_pass(const EmCpArgs& a, int prec, double* ws, double* out4, hipStream_t s) {
   AO_REQUIRE(a.R >= 1 && a.R <= kMaxRank && a.I > 0 && a.J > 0 && a.K > 0, "em_cp_pass: bad sizes");
-  AO_REQUIRE(a.K <= 65535, "em_cp_pass: third mode too long for one launch");
-  const bool wide = a.R <= 32;                       // VEC rows of A in registers; beyond 32 columns one row per thread
-  const int vec = !wide ? 1 : (prec == AOADMM_PREC_F32 ? 4 : 2);
+  AO_REQUIRE(a.K <= 65535 && a.J <= 65535, "em_cp_pass: mode too long for one launch");
+  const bool fuse = a.T != nullptr;
+  const bool wj = a.walk != 2;
+  AO_REQUIRE(!fuse || em_cp_can_fuse(a, prec), "em_cp_pass: this block cannot take the fused contraction");
+  AO_REQUIRE(wj || a.C != nullptr, "em_cp_pass: a matrix block has no third mode to walk");
+  const int vec = em_vec(a, prec);
   const int64_t strips = cdiv(a.Ipad, (int64_t)kEmThreads * vec);
   int jchunks; int64_t jlen;
-  em_chunking(strips, a.J, a.K, &jchunks, &jlen);
-  const dim3 grid((unsigned)(strips * jchunks), (unsigned)a.K);
+  em_chunking(strips, wj ? a.J : a.K, wj ? a.K : a.J, fuse, &jchunks, &jlen);
+  const dim3 grid((unsigned)(strips * jchunks), (unsigned)(wj ? a.K : a.J));
   AO_REQUIRE((size_t)grid.x * grid.y * 4 * sizeof(double) <= em_cp_ws_bytes(a.Ipad, a.J, a.K), "em_cp_pass: workspace");
   if (prec == AOADMM_PREC_F32) {
-    if (wide) em_cp_launch<float, 4>(a, jchunks, jlen, ws, grid, s);
+    if (fuse) em_cp_launch<float, 4, true>(a, jchunks, jlen, ws, grid, s);
+    else if (em_wide(a)) em_cp_launch<float, 4, false>(a, jchunks, jlen, ws, grid, s);
     else em_cp_k<float, 64><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws);
   } else {
-    if (wide) em_cp_launch<double, 2>(a, jchunks, jlen, ws, grid, s);
+    if (fuse) em_cp_launch<double, 2, true>(a, jchunks, jlen, ws, grid, s);
+    else if (em_wide(a)) em_cp_launch<double, 2, false>(a, jchunks, jlen, ws, grid, s);
     else em_cp_k<double, 64><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws);
   }
   AO_KERNEL_CHECK();

@@ -247,7 +247,7 @@ class Engine {
   void coupled_admm(int c, const aoadmm_options& opt);
   void eval_objective_enqueue(bool first);
   bool has_missing() const;
-  void em_pass_enqueue(int p, int update);         // statistics of tensor p into its EM slots (+ imputation)
+  void em_pass_enqueue(int p, int update, bool fuse_next_pass = false);         // statistics of tensor p into its EM slots (+ imputation)
   double* em_slot(int p) const;
   void ensure_mode_work(ModeInfo& mi);
   // PARAFAC2 (solver_par2.hip)

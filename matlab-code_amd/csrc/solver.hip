@@ -704,9 +704,11 @@ double* Engine::em_slot(int p) const {
   return slots_.d() + n_modes_ * (kSlotsPerMode + kResidPerMode) + 2 * n_tensors_ + 16 + 4 * p;
 }
 
+static int next_update_distance(int pos, int c, const int* seq, int n);
+
 // One EM pass over tensor p with the current factors: {num, den, obs_res, obs_x2} -> em_slot(p), all-reduced
 // over the row shards; update = 1 also overwrites the missing entries with the model (:416-435).
-void Engine::em_pass_enqueue(int p, int update) {
+void Engine::em_pass_enqueue(int p, int update, bool fuse_next_pass) {
   TensorInfo& t = tensors_[p];
   if (t.par2) {
     Par2Block& b = t.p2;
@@ -748,6 +750,32 @@ void Engine::em_pass_enqueue(int p, int update) {
     a.C = cur; a.ldC = curK; a.K = curK;
   }
   emws_.ensure(em_cp_ws_bytes(a.Ipad, a.J, a.K));
+  // The imputation pass reads and rewrites the whole block: it can leave the partial contraction the next outer
+  // iteration starts with (the pass that serves the first mode it updates), taken from the values it writes back.
+  // Contracted mode: 2 or 3 (the strip kernel vectorises mode 1), the one whose factor stays unchanged longest.
+  int fused_c = -1;
+  ContractPlan fpl;
+  FactorRef facs[8];
+  static const bool no_fuse = getenv("AOADMM_NO_EM_FUSE") != nullptr;       // development switch (tools/time_em.py)
+  if (fuse_next_pass && update && b.nd == 3 && !no_fuse && em_cp_can_fuse(a, b.X.prec)) {
+    for (int i = 0; i < t.nmodes; ++i) facs[i] = factor_ref(modes_[t.modes[i]]);
+    const std::vector<int> seq = update_sequence(p);
+    const int pos0 = seq.empty() ? 0 : seq[0];
+    int best = -1;
+    for (int cand = 2; cand >= 1; --cand) {
+      if (cand == pos0) continue;
+      const int dist = next_update_distance(pos0, cand, seq.data(), (int)seq.size());
+      if (dist > best) { best = dist; fused_c = cand; }
+    }
+    const int64_t J = b.dims[1], K = b.dims[2];
+    a.walk = fused_c == 1 ? 1 : 2;
+    fpl = fused_c == 2 ? make_plan(1, 0, a.Ipad * J, a.Ipad * J, K, a.R, b.X.prec)
+                       : make_plan(K, a.Ipad * J, a.Ipad, a.Ipad, J, a.R, b.X.prec);
+    fpl.nchunk = em_cp_fused_chunks(a, b.X.prec);
+    b.T.ensure(fpl.t_bytes());
+    a.T = b.T.p;
+    a.t_chunk_stride = fpl.trows() * a.R;
+  }
   em_cp_pass(a, b.X.prec, emws_.d(), em_slot(p), stream_);
   if (b.nd == 2 && update) {
     // same imputation on the transposed copy (roles of the two factors swapped); its statistics are discarded
@@ -761,6 +789,7 @@ void Engine::em_pass_enqueue(int p, int update) {
   }
   allreduce(em_slot(p), 4);
   if (update) b.cached_mode = -1;                    // the data changed: cached partial contractions are stale
+  if (fused_c >= 0) { b.cached_mode = fused_c; b.cached_version = facs[fused_c].version; b.plan = fpl; }
 }
 
 // ---------------------------------------------------------------------------
@@ -2940,7 +2969,8 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     }
     if (has_miss)                                                              // EM imputation (:408-441)
       for (int p = 0; p < n_tensors_; ++p)
-        if (tensors_[p].par2 ? tensors_[p].p2.has_mask : tensors_[p].blk.has_mask) em_pass_enqueue(p, 1);
+        if (tensors_[p].par2 ? tensors_[p].p2.has_mask : tensors_[p].blk.has_mask)
+          em_pass_enqueue(p, 1, opt.use_dimtree != 0 && iter < opt.MaxOuterIters);
     for (int i = 0; i < 4; ++i) fo[i] = f[i];
     if (iter < opt.MaxOuterIters) {
       // The objective needs nothing the first tensor pass of the next iteration writes (frag, T), and that pass does
