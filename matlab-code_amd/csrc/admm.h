@@ -80,6 +80,31 @@ void admm_constrained_loop(const AdmmMode& m, double* part, double* V, double* Z
                            AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du, hipStream_t s,
                            LoopEnd* deferred_end = nullptr, GramFold* gf = nullptr);
 
+// One-workgroup form of the same loop for short modes (admm.hip admm_loop_wg_k): rows <= 256 and R <= 16; element-/row-wise
+// prox or the column-norm family.  One launch for the loop, the Gram matrix and the
+// row-major copy of the new factor.
+struct WgLoopU {
+  const double* A;          // right-hand side, rows x R column-major (ld = rows)
+  const double* Binv;       // inv(L*L'), R x R (shared system), or null
+  const double* L;          // Cholesky factor: R x R (shared, used when Binv is null) or [rows][R*R] with per_row
+  const double* rho;        // device scalar, or one value per row with per_row
+  const double* rho_prox;   // device scalar the prox sees (max(rho) for a PARAFAC2 C mode, :1423-1424)
+  double *fac, *Z, *mu;     // rows x R each
+  int64_t rows;
+  int R;
+  int per_row;              // 1: row k has its own system L_k and rho_k (:602-606)
+  int ptype;
+  double p0, p1;
+  int max_inner;
+  double tol_pr, tol_du;
+  AdmmCtl* ctl;             // active != 0 on entry; receives iters, res[1], res[3], active = 0
+  int reset = 0;            // 1: run whatever ctl holds (the caller would otherwise launch ctl_reset first)
+  double* gram;             // out: fac'*fac (R x R), or null
+  double* facT;             // out: row-major copy of fac (rows x R), or null
+};
+bool admm_loop_wg_ok(int64_t rows, int R, int ptype, int max_inner);
+void admm_loop_wg(const WgLoopU& a, hipStream_t s);
+
 // generic pieces for the coupled / PARAFAC2 loops -------------------------------
 // (Z,mu) <- update_constraint (:1420-1429): Zold kept in `Zold`; slots[0..3] receive
 // ||fac-Z||^2, ||fac||^2, ||mu||^2, ||Z-Zold||^2

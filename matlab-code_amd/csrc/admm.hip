@@ -1300,6 +1300,263 @@ static void launch_row_iteration(const FusedArgs& a, unsigned blocks, hipStream_
   }
 }
 
+// ---------------------------------------------------------------------------
+// Short modes: the whole ADMM_constrained_only loop (:596-622) in ONE launch of one workgroup, thread = row, the row's
+// operands (A, Z, mu, fac) in registers for the length of the loop.  Per inner iteration: A_inner (:608), the solve
+// (:609; inv(L*L') or L from LDS, or the row's own factor for the per-row systems of a PARAFAC2 C mode, :602-606),
+// update_constraint (:1420-1429) for the element-/row-wise catalogue and the column-norm family (column sums through
+// one workgroup reduction), the four sums of eval_res_ADMM_constr (:1079-1096) through a second one, and the while
+// test (:600) -- every thread holds the same totals, so the decision needs no further exchange.  At the end the
+// kernel also leaves the Gram matrix of the new factor and its row-major copy (what atb_small would compute, :148).
+// Replaces 2 launches per loop (element-wise prox), 3 per inner iteration (column-norm prox, PARAFAC2 C mode) plus
+// the two Gram launches.  Sums run over waves in a fixed order: results do not depend on timing.
+// ---------------------------------------------------------------------------
+static constexpr int kWgLoopRows = 256;             // one row per thread: longer modes keep the multi-workgroup loops
+static bool prox_is_colnorm(int t) {
+  return t == AOADMM_C_L2_BALL || t == AOADMM_C_NONNEG_L2_BALL || t == AOADMM_C_NONNEG_L2_SPHERE || t == AOADMM_C_L2_REG;
+}
+
+// totals of NV per-thread values over the workgroup, the same in every thread (butterfly inside the wave, waves in
+// index order through LDS)
+template <int NV, int NW>
+__device__ __forceinline__ void wg_sum(double (&v)[NV], double* red /* [NW][NV] */) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+  if (NW == 1) return;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[w * NV + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double x = 0.0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) x += red[q * NV + k];
+    v[k] = x;
+  }
+  __syncthreads();
+}
+
+template <int RMAX, int NT>
+__global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
+  constexpr int NW = NT / 64;
+  extern __shared__ double lds[];                    // M[RMAX*RMAX] | red[NW][max(RMAX,4)] | fsh[rows][RP] (Gram)
+  constexpr int NRED = RMAX > 4 ? RMAX : 4;
+  double* Msh = lds;
+  double* red = lds + RMAX * RMAX;
+  double* fsh = red + NW * NRED;
+  AdmmCtl* ctl = a.ctl;
+  if (!a.reset && ctl->active == 0) return;          // a failed factorisation (sys_build) leaves the state untouched
+  const int t = threadIdx.x;
+  const int R = a.R;
+  const int64_t rows = a.rows;
+  const bool have = t < rows;
+  const int64_t i = have ? t : rows - 1;             // clamped: padding threads compute on the last row, store nothing
+  double av[RMAX], z[RMAX], mu[RMAX], x[RMAX];
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c) {
+    const int64_t o = i + rows * (c < R ? c : 0);
+    av[c] = a.A[o]; z[c] = a.Z[o]; mu[c] = a.mu[o];
+    x[c] = 0.0;
+  }
+  const double* Msrc = a.Binv ? a.Binv : a.L;
+  if (!a.per_row)
+    for (int e = t; e < R * R; e += NT) Msh[e] = Msrc[e];
+  const double rho = a.per_row ? a.rho[i] : a.rho[0];
+  const double rho_prox = a.rho_prox[0];             // max(rho) of a PARAFAC2 C mode (:1423-1424); rho otherwise
+  const double rh = rho / 2;
+  const ElemProx ep = elem_prox_of(a.ptype, a.p0, a.p1, rho_prox);
+  const bool colnorm = a.ptype == AOADMM_C_L2_BALL || a.ptype == AOADMM_C_NONNEG_L2_BALL ||
+                       a.ptype == AOADMM_C_NONNEG_L2_SPHERE || a.ptype == AOADMM_C_L2_REG;
+  const bool clampv = a.ptype == AOADMM_C_NONNEG_L2_BALL || a.ptype == AOADMM_C_NONNEG_L2_SPHERE;
+  __syncthreads();
+  double pr = 0.0, du = 0.0;
+  int it = 0;
+  for (;;) {
+    // the system matrix is re-read (LDS / L1) every iteration: hoisted out of the loop its R*R entries alone would
+    // take more registers than the row operands (compiler barrier)
+    asm volatile("" ::: "memory");
+    // A_inner = A + rho/2*(Z - mu) (:608) and the solve (:609)
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) x[c] = c < R ? av[c] + rh * (z[c] - mu[c]) : 0.0;
+    if (a.per_row) {
+      const double* Lk = a.L + i * (int64_t)R * R;
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        if (r < R) {
+          double v = x[r];
+#pragma unroll
+          for (int q = 0; q < RMAX; ++q)
+            if (q < r) v -= Lk[r + R * q] * x[q];
+          x[r] = v / Lk[r + R * r];
+        }
+      }
+#pragma unroll
+      for (int r = RMAX - 1; r >= 0; --r) {
+        if (r < R) {
+          double v = x[r];
+#pragma unroll
+          for (int q = 0; q < RMAX; ++q)
+            if (q > r && q < R) v -= Lk[q + R * r] * x[q];
+          x[r] = v / Lk[r + R * r];
+        }
+      }
+    } else if (a.Binv) {
+      double y[RMAX];
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) {
+        double acc = 0.0;
+        if (c < R) {
+#pragma unroll
+          for (int q = 0; q < RMAX; ++q)
+            if (q < R) acc += x[q] * Msh[q + R * c];
+        }
+        y[c] = acc;
+      }
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) x[c] = y[c];
+    } else {
+      row_solve_regs2<RMAX>(x, Msh, R);
+    }
+    // update_constraint (:1420-1429): Z = prox(fac + mu), mu += fac - Z
+    double zn[RMAX];
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) zn[c] = x[c] + mu[c];
+    if (colnorm) {
+      double cs[RMAX];
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) {
+        const double y = clampv ? fmax(zn[c], 0.0) : zn[c];
+        cs[c] = have && c < R ? y * y : 0.0;
+      }
+      wg_sum<RMAX, NW>(cs, red);
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) {
+        if (c >= R) continue;
+        const double nrm = sqrt(cs[c]);
+        const double y = clampv ? fmax(zn[c], 0.0) : zn[c];
+        if (a.ptype == AOADMM_C_NONNEG_L2_SPHERE) {
+          if (nrm == 0.0) {
+            // all-zero column: unit vector at the first maximum of the input (prox_normalized_nonneg.m:5-7)
+            double bv = have ? zn[c] : -INFINITY;
+            int bi = have ? t : 0x7fffffff;
+            for (int off = 32; off > 0; off >>= 1) {
+              const double ov = __shfl_xor(bv, off);
+              const int oi = __shfl_xor(bi, off);
+              if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (NW > 1) {
+              int* ired = reinterpret_cast<int*>(red + NW);
+              if ((t & 63) == 0) { red[t >> 6] = bv; ired[t >> 6] = bi; }
+              __syncthreads();
+              bv = red[0]; bi = ired[0];
+              for (int q = 1; q < NW; ++q)
+                if (red[q] > bv || (red[q] == bv && ired[q] < bi)) { bv = red[q]; bi = ired[q]; }
+              __syncthreads();
+            }
+            zn[c] = t == bi ? 1.0 : 0.0;
+          } else {
+            zn[c] = y / nrm;
+          }
+        } else {
+          double scale;
+          if (a.ptype == AOADMM_C_L2_REG) {
+            const double g = a.p0 / rho_prox;
+            scale = nrm > g ? 1.0 - g / nrm : 0.0;
+          } else {
+            scale = nrm > a.p0 ? a.p0 / nrm : 1.0;
+          }
+          zn[c] = y * scale;
+        }
+      }
+    } else if (a.ptype == AOADMM_C_SIMPLEX_ROW) {
+      simplex_regs<RMAX>(zn, R, a.p0);
+    } else {
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) zn[c] = elem_prox(ep, zn[c]);
+    }
+    double sm[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) {
+      if (c < R) {
+        const double mn = mu[c] + x[c] - zn[c];
+        const double d = x[c] - zn[c], e = zn[c] - z[c];
+        if (have) { sm[0] += d * d; sm[1] += x[c] * x[c]; sm[2] += mn * mn; sm[3] += e * e; }
+        mu[c] = mn; z[c] = zn[c];
+      }
+    }
+    wg_sum<4, NW>(sm, red);
+    pr = sqrt(sm[0]) / sqrt(sm[1]);                                          // :1085
+    const double sc = sqrt(sm[2]);
+    du = sc > 0 ? sqrt(sm[3]) / sc : sqrt(sm[3]);                            // :1087-1092
+    ++it;
+    if (!(it < a.max_inner && (pr > a.tol_pr || du > a.tol_du))) break;      // :600
+  }
+  if (have) {
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) {
+      if (c < R) {
+        const int64_t o = i + rows * c;
+        a.fac[o] = x[c]; a.Z[o] = z[c]; a.mu[o] = mu[c];
+      }
+    }
+  }
+  if (t == 0) {
+    ctl->res[0] = 0.0; ctl->res[1] = pr; ctl->res[2] = 0.0; ctl->res[3] = du;
+    ctl->iters = it;
+    ctl->active = 0;
+  }
+  if (a.gram == nullptr) return;
+  // Gram matrix fac'*fac (:148) and the row-major copy of fac: rows through LDS, one (p, q) pair per wave at a time
+  constexpr int RP = RMAX | 1;
+  if (have) {
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c) {
+      fsh[t * RP + c] = c < R ? x[c] : 0.0;
+      if (c < R && a.facT) a.facT[(int64_t)t * R + c] = x[c];
+    }
+  }
+  __syncthreads();
+  const int lane = t & 63, w = t >> 6;
+  const int npairs = R * (R + 1) / 2;
+  for (int e = w; e < npairs; e += NW) {
+    int p = 0, rem = e;                                // e -> (p, q), p <= q, row-wise over the upper triangle
+    while (rem >= R - p) { rem -= R - p; ++p; }
+    const int q = p + rem;
+    double acc = 0.0;
+    for (int64_t r0 = lane; r0 < rows; r0 += 64) acc += fsh[r0 * RP + p] * fsh[r0 * RP + q];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) { a.gram[p + R * q] = acc; a.gram[q + R * p] = acc; }
+  }
+}
+
+size_t admm_loop_wg_lds(int rmax, int nt, int64_t rows, bool gram) {
+  const int nred = rmax > 4 ? rmax : 4;
+  return ((size_t)rmax * rmax + (size_t)(nt / 64) * nred + (gram ? (size_t)rows * (rmax | 1) : 0)) * sizeof(double);
+}
+
+bool admm_loop_wg_ok(int64_t rows, int R, int ptype, int max_inner) {
+  static const bool off = getenv("AOADMM_NO_WG_LOOP") != nullptr;          // development switch
+  if (off || max_inner < 1) return false;
+  if (!(prox_is_fusable(ptype) || prox_is_colnorm(ptype))) return false;
+  return rows <= kWgLoopRows && R <= 16;
+}
+
+void admm_loop_wg(const WgLoopU& a, hipStream_t s) {
+  AO_REQUIRE(admm_loop_wg_ok(a.rows, a.R, a.ptype, a.max_inner), "admm_loop_wg: mode too large for the one-workgroup loop");
+  const bool gram = a.gram != nullptr;
+  auto go = [&](auto kern, int rmax) {
+    const size_t lds = admm_loop_wg_lds(rmax, kWgLoopRows, a.rows, gram);
+    kern<<<1, kWgLoopRows, lds, s>>>(a);
+  };
+  if (a.R <= 4) go(admm_loop_wg_k<4, kWgLoopRows>, 4);
+  else if (a.R <= 8) go(admm_loop_wg_k<8, kWgLoopRows>, 8);
+  else go(admm_loop_wg_k<16, kWgLoopRows>, 16);
+  AO_KERNEL_CHECK();
+}
+
 void admm_constrained_loop(const AdmmMode& m, double* part, double* V, double* Znew, double* prox_ws,
                            AdmmCtl* ctl, int max_inner, double tol_pr, double tol_du, hipStream_t s,
                            LoopEnd* deferred_end, GramFold* gf) {

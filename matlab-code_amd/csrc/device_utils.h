@@ -59,4 +59,21 @@ __device__ __forceinline__ double block256_sum(double v, double* sh4) {
   return r;
 }
 
+// Sum over the 64 lanes of a FULL wavefront, returned in every lane, by DPP moves (v_mov_b32_dpp, a few cycles each)
+// instead of six dependent ds_bpermute round trips: inclusive sums move towards higher lanes inside rows of 16
+// (row_shr 1, 2, 4, 8 with zeros shifted in), the row totals cross rows (row_bcast:15 into rows 1 and 3, row_bcast:31
+// into rows 2 and 3), lane 63 holds the total.  Fixed order.  All 64 lanes must be active.
+__device__ __forceinline__ double wave_sum(double v) {
+  v += __builtin_amdgcn_update_dpp(0.0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0.0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0.0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0.0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0.0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0.0, v, 0x143, 0xc, 0xf, false);
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)bits, 63);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(bits >> 32), 63);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 }  // namespace aoadmm

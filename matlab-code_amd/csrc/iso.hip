@@ -19,7 +19,7 @@
 // this library's first version) walks each column sequentially.
 // Quirks of project_unimodal_vector.m that change numbers are kept: blocks merge on equal levels (:63), the split
 // criterion pairs the left prefix 1..i with the right prefix of length n-i+1 for i >= 2 and uses the right fit alone
-// for i = 1 (:22-26), the first minimum wins, the right part is rebuilt with length n-i (:16), and with
+// for i = 1 (:22-26), the first minimum wins (ties up to the rounding of the error sums: see prox_iso_k), the right part is rebuilt with length n-i (:16), and with
 // non-negativity a prefix whose last level is negative gets the error sum_{t < i-1} s_t^2 (:70, one term short).
 #include "admm.h"
 #include "device_utils.h"
@@ -62,14 +62,14 @@ __device__ __forceinline__ double wg_exscan(double v, double& total, double* sc)
 }
 
 struct IsoBuf {          // per direction: survives until the column is written
-  double* P;             // n + 1 centred prefix sums
+  double* P;             // n + 1 prefix sums
   int* PV;               // n + 1: prev(i)
   unsigned char* FL;     // n + 1: node thresholded to zero (non-negativity)
-  double c;              // mean of the sequence
+  double c;              // offset the sums were taken about (0: plain sums)
 };
 
-// Step 1 for one direction: the sequence s_t = sign * src[flip ? n-1-t : t] (parked in `park`), its centred prefix
-// sums P, the prefix sums of squares Q and the mean c.
+// Step 1 for one direction: the sequence s_t = sign * src[flip ? n-1-t : t] (parked in `park`), its prefix sums P and
+// the prefix sums of squares Q.
 template <int NTH>
 __device__ void iso_prefix(const double* __restrict__ src, int n, bool flip, double sign, IsoBuf& b, double* Q, double* park,
                            double* sc) {
@@ -83,13 +83,13 @@ __device__ void iso_prefix(const double* __restrict__ src, int n, bool flip, dou
     loc += s;
     loc2 += s * s;
   }
+  // Plain (uncentred) sums, like the reference's sumwy / sumwy2 (:45-46, :83-85): on data with exact ties -- integers,
+  // quantised measurements -- the sums, the slope comparisons of iso_prev and the block levels are then exact, so equal
+  // levels merge exactly as the reference merges them (:63).  Sums about the mean were more accurate for columns with a
+  // large offset but turned every exact tie into a coin flip.
   double tot, tot2;
-  (void)wg_exscan<NTH>(loc, tot, sc);
-  const double c = tot / n;
-  double locc = 0.0;
-  for (int i = c0; i < c1; ++i) locc += park[i] - c;
-  double dummy;
-  double run = wg_exscan<NTH>(locc, dummy, sc);
+  const double c = 0.0;
+  double run = wg_exscan<NTH>(loc, tot, sc);
   double run2 = wg_exscan<NTH>(loc2, tot2, sc);
   for (int i = c0; i < c1; ++i) {
     const double s = park[i];
@@ -289,22 +289,27 @@ __global__ __launch_bounds__(NTH) void prox_iso_k(IsoCol a, int mode, IsoPrevOut
   const double* ErrR = iso_errors<NTH>(n, Ea, Eb, Ja, Jb);
   // split: i = 1 pairs nothing with the right fit of the whole column, i >= 2 the left prefix of length i with the
   // right prefix of length n-i+1 (:22-26); the first minimum wins
+  // Splits whose criterion differs only by the rounding of the error sums are ties: the reference takes the first
+  // minimum of ITS sums (accumulated pool by pool along each prefix), which on exactly tied data -- integers,
+  // quantised measurements -- is decided by rounding noise no other summation order reproduces.  Here: the smallest i
+  // among the splits within a few ulp of the minimum, i.e. the first minimum of the exact criterion.
+  auto crit = [&](int i) { return i == 1 ? ErrR[n] : ErrL[i] + ErrR[n - i + 1]; };
   double be = INFINITY;
-  int bi = 0x7fffffff;
-  for (int i = 1 + threadIdx.x; i <= n; i += NTH) {
-    const double e = i == 1 ? ErrR[n] : ErrL[i] + ErrR[n - i + 1];
-    if (e < be) { be = e; bi = i; }                  // ascending i per thread: keeps the first minimum
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    const double oe = __shfl_xor(be, off);
-    const int oi = __shfl_xor(bi, off);
-    if (oe < be || (oe == be && oi < bi)) { be = oe; bi = oi; }
-  }
-  if ((threadIdx.x & 63) == 0) { best_e[threadIdx.x >> 6] = be; best_i[threadIdx.x >> 6] = bi; }
+  for (int i = 1 + threadIdx.x; i <= n; i += NTH) be = fmin(be, crit(i));
+  for (int off = 32; off > 0; off >>= 1) be = fmin(be, __shfl_xor(be, off));
+  if ((threadIdx.x & 63) == 0) best_e[threadIdx.x >> 6] = be;
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < NTH / 64; ++k)
-    if (best_e[k] < be || (best_e[k] == be && best_i[k] < bi)) { be = best_e[k]; bi = best_i[k]; }
+  for (int k = 0; k < NTH / 64; ++k) be = fmin(be, best_e[k]);
+  const double lim = be + 16.0 * 2.220446049250313e-16 * fabs(be);
+  int bi = 0x7fffffff;
+  for (int i = 1 + threadIdx.x; i <= n; i += NTH)
+    if (crit(i) <= lim) { bi = i; break; }           // ascending i per thread
+  for (int off = 32; off > 0; off >>= 1) bi = min(bi, __shfl_xor(bi, off));
+  if ((threadIdx.x & 63) == 0) best_i[threadIdx.x >> 6] = bi;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NTH / 64; ++k) bi = min(bi, best_i[k]);
   const int split = bi;                              // same value in every thread
   __syncthreads();
   iso_write<NTH>(n, split, bl, Ja, Jb, M, false, 1.0, z, sci);                  // :15

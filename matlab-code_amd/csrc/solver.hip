@@ -1361,6 +1361,21 @@ void Engine::update_uncoupled_cp_mode(int m, const aoadmm_options& opt) {
   if (!mi.constrained) {
     // G.fac{m} = A{m}/B{m}  (:134): B is symmetric positive definite -> Cholesky solve
     row_solve(mi.fac.d(), mi.rows, mi.Aeff, mi.rows, mi.L.d(), mi.rows, mi.R, nullptr, stream_);
+  } else if (admm_loop_wg_ok(mi.rows, mi.R, mi.prox.type, opt.MaxInnerIters)) {
+    // short mode: loop, Gram matrix and row-major copy in one launch of one workgroup
+    WgLoopU wa;
+    wa.A = mi.Aeff; wa.Binv = mi.Binv.d(); wa.L = mi.L.d(); wa.rho = mi.rho.d(); wa.rho_prox = mi.rho.d();
+    wa.fac = mi.fac.d(); wa.Z = mi.Z.d(); wa.mu = mi.mu.d();
+    wa.rows = mi.rows; wa.R = mi.R; wa.per_row = 0;
+    wa.ptype = mi.prox.type; wa.p0 = mi.prox.p0; wa.p1 = mi.prox.p1;
+    wa.max_inner = opt.MaxInnerIters; wa.tol_pr = opt.innerRelPrTol_constr; wa.tol_du = opt.innerRelDualTol_constr;
+    wa.ctl = ctl;
+    mi.facT.ensure((size_t)mi.rows * mi.R * sizeof(double));
+    wa.gram = mi.gram.d(); wa.facT = mi.facT.d();
+    admm_loop_wg(wa, stream_);
+    mi.version++;
+    mi.facT_version = mi.version;
+    return;
   } else {
     AdmmMode am;
     am.A = mi.Aeff; am.L = mi.L.d(); am.Binv = mi.Binv.d(); am.rho = mi.rho.d();
@@ -1968,13 +1983,12 @@ __global__ __launch_bounds__(256) void couple_loop_wg_k(WgLoopArgs a) {
         }
       }
     }
-    // ---- the workgroup's sums (fixed order: lanes by butterfly, then the four waves in order)
+    // ---- the workgroup's sums (fixed order: lanes by DPP tree, then the four waves in order)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        double v = sums[j][k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        const double v = wave_sum(sums[j][k]);
         if (lane == 0) red[w][j * 8 + k] = v;
       }
     __syncthreads();
@@ -2236,13 +2250,12 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
         for (int r = 0; r < RMAX; ++r) sums[j][1] += f[j][r] * f[j][r];
       }
     }
-    // ---- the workgroup's sums (fixed order: lanes by butterfly, then the four waves in order)
+    // ---- the workgroup's sums (fixed order: lanes by DPP tree, then the four waves in order)
 #pragma unroll
     for (int j = 0; j < NM; ++j)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        double v = sums[j][k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        const double v = wave_sum(sums[j][k]);
         if (lane == 0) red[w][j * 8 + k] = v;
       }
     __syncthreads();

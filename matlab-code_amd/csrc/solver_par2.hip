@@ -220,6 +220,20 @@ void Engine::par2_update_C(int m, const aoadmm_options& opt) {
   par2_rho_max(b.rhoc.d(), b.K, b.rhomax.d(), stream_);
   const P2Dims dall = b.dims_all();                   // the K x R row systems are solved on every rank
   t.last_pos = 2;                                                                        // last_m(p) = 3
+  if (mi.constrained && admm_loop_wg_ok(mi.rows, mi.R, mi.prox.type, opt.MaxInnerIters)) {
+    // K <= 256 rows: the K row systems, update_constraint with max(rho) and the loop test in one launch (:602-606)
+    WgLoopU wa;
+    wa.A = b.ac.d(); wa.Binv = nullptr; wa.L = b.Lc.d(); wa.rho = b.rhoc.d(); wa.rho_prox = b.rhomax.d();
+    wa.fac = mi.fac.d(); wa.Z = mi.Z.d(); wa.mu = mi.mu.d();
+    wa.rows = mi.rows; wa.R = mi.R; wa.per_row = 1;
+    wa.ptype = mi.prox.type; wa.p0 = mi.prox.p0; wa.p1 = mi.prox.p1;
+    wa.max_inner = opt.MaxInnerIters; wa.tol_pr = opt.innerRelPrTol_constr; wa.tol_du = opt.innerRelDualTol_constr;
+    wa.ctl = ctl; wa.reset = 1;
+    wa.gram = nullptr; wa.facT = nullptr;
+    admm_loop_wg(wa, stream_);
+    mi.version++;
+    return;
+  }
   ctl_reset(ctl, stream_);
   if (!mi.constrained) {
     par2_c_rowsolve(b.ac.d(), b.rhoc.d(), b.Lc.d(), nullptr, nullptr, 0, dall, mi.fac.d(), nullptr, stream_);   // :236
