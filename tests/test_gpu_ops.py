@@ -65,7 +65,7 @@ CASES = [
 def test_prox_matches_oracle(eng, c, shape):
     """Every device prox equals the oracle's operator to 1e-10 (they are exact algorithms;
     differences are summation order only)."""
-    rng = np.random.default_rng(hash(c[0]) % 1000 + shape[0])
+    rng = np.random.default_rng(zlib.crc32(c[0].encode()) % 1000 + shape[0])   # not hash(): it changes per process
     X = rng.standard_normal(shape)
     if c[0] == 'orthonormal' and shape[0] < shape[1]:
         pytest.skip('needs rows >= cols')
