@@ -377,9 +377,9 @@ static void em_cp_launch(const EmCpArgs& a, int jchunks, int64_t jlen, double* w
 
 void em_cp_pass(const EmCpArgs& a, int prec, double* ws, double* out4, hipStream_t s) {
   AO_REQUIRE(a.R >= 1 && a.R <= kMaxRank && a.I > 0 && a.J > 0 && a.K > 0, "em_cp_pass: bad sizes");
-  AO_REQUIRE(a.K <= 65535 && a.J <= 65535, "em_cp_pass: mode too long for one launch");
   const bool fuse = a.T != nullptr;
   const bool wj = a.walk != 2;
+  AO_REQUIRE((wj ? a.K : a.J) <= 65535, "em_cp_pass: mode too long for one launch");   // grid.y = the fixed index
   AO_REQUIRE(!fuse || em_cp_can_fuse(a, prec), "em_cp_pass: this block cannot take the fused contraction");
   AO_REQUIRE(wj || a.C != nullptr, "em_cp_pass: a matrix block has no third mode to walk");
   const int vec = em_vec(a, prec);

@@ -757,7 +757,8 @@ void Engine::em_pass_enqueue(int p, int update, bool fuse_next_pass) {
   ContractPlan fpl;
   FactorRef facs[8];
   static const bool no_fuse = getenv("AOADMM_NO_EM_FUSE") != nullptr;       // development switch (tools/time_em.py)
-  if (fuse_next_pass && update && b.nd == 3 && !no_fuse && em_cp_can_fuse(a, b.X.prec)) {
+  if (fuse_next_pass && update && b.nd == 3 && !no_fuse && em_cp_can_fuse(a, b.X.prec) && b.dims[1] <= 65535 &&
+      b.dims[2] <= 65535) {
     for (int i = 0; i < t.nmodes; ++i) facs[i] = factor_ref(modes_[t.modes[i]]);
     const std::vector<int> seq = update_sequence(p);
     const int pos0 = seq.empty() ? 0 : seq[0];
