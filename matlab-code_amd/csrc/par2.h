@@ -50,6 +50,11 @@ struct P2BArgs {
 // psum (R*R+1 doubles) != nullptr: slabs are sharded, DeltaB's sums go through `allreduce`
 void par2_b_iteration(const P2BArgs& a, const P2Dims& d, const AdmmCtl* ctl, hipStream_t s, double* psum,
                       const P2AllReduce& allreduce);
+// The whole loop without B_k constraints on unsharded slabs, R <= 8: two launches per inner iteration (the sum over the
+// slabs and the while test ride at the head of the next kernel) and one closing launch; ctl must have been reset.
+bool par2_b_loop_folded_ok(const P2Dims& d, bool constrained, bool sharded);
+void par2_b_loop_folded(const P2BArgs& a, const P2Dims& d, AdmmCtl* ctl, int max_inner, double tol_pr_coupl,
+                        double tol_pr_constr, double tol_du_coupl, double tol_du_constr, hipStream_t s);
 // Z_k = prox(B_k + muZ_k, rho_k) ; muZ_k += B_k - Z_k ; norms[k][4..6] = ||B-Z||^2, ||muZ||^2, ||Z-Zold||^2   (:566-579)
 void par2_b_constraint(const ProxSpec& ps, const double* B, double* Z, double* muZ, double* Zold, double* V,
                        const double* rho, const P2Dims& d, double* prox_ws, double* norms, const AdmmCtl* ctl,

@@ -406,6 +406,158 @@ __global__ __launch_bounds__(kP2Threads) void par2_b_dual_k(P2BArgs a, P2Dims d,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Two launches per inner iteration instead of four (unconstrained B_k, slabs not sharded, R <= 8): the sum over the
+// slabs that finishes DeltaB (:537-544) moves to the head of the dual kernel and the residual means with the while
+// test (:520, :583-584) to the head of the NEXT iteration's slab kernel.  Every workgroup recomputes the same small sums
+// from the same data in the same order, so all of them hold the same DeltaB and take the same decision; workgroup 0
+// publishes them.  DeltaB alternates between the two buffers by iteration parity (a workgroup may still be reading the
+// old one while workgroup 0 writes the new one); par2_b_close_k records the last iteration's residuals and moves the
+// final pair into place.
+// ---------------------------------------------------------------------------
+struct P2Fold {
+  int it, max_inner;
+  double tpc, tpz, tdc, tdz;
+};
+// while test at the head of iteration `it` from the norms iteration it-1 left (kP2Threads = 64 lanes, all active)
+__device__ __forceinline__ bool par2_b_head(const double* norms, const P2Dims& d, const P2Fold& f, AdmmCtl* ctl, bool writer) {
+  const int active = ctl->active;
+  if (f.it == 0) return active != 0;
+  double pc = 0.0, dc = 0.0;
+  for (int k = d.k0 + (int)threadIdx.x; k < d.k1; k += kP2Threads) {
+    const double* nk = norms + (int64_t)k * 8;
+    pc += sqrt(nk[0]) / sqrt(nk[1]) / d.K;                      // :583
+    dc += sqrt(nk[2]) / sqrt(nk[3]) / d.K;                      // :584 (no zero check in the reference)
+  }
+  pc = wave_sum(pc); dc = wave_sum(dc);
+  const bool cont = f.it < f.max_inner && (pc > f.tpc || 0.0 > f.tpz || dc > f.tdc || 0.0 > f.tdz);   // :520
+  if (writer && active) {
+    ctl->res[0] = pc; ctl->res[1] = 0.0; ctl->res[2] = dc; ctl->res[3] = 0.0;
+    ctl->iters = f.it;
+    if (!cont) ctl->active = 0;
+  }
+  return active != 0 && cont;
+}
+template <int RMAX>
+__global__ __launch_bounds__(kP2Threads) void par2_b_slab_fold_k(P2BArgs a, P2Dims d, AdmmCtl* ctl, int in_lds, P2Fold f) {
+  extern __shared__ double sh[];
+  if (!par2_b_head(a.norms, d, f, ctl, blockIdx.x == 0 && threadIdx.x == 0)) return;   // the same in every workgroup
+  const int k = d.k0 + blockIdx.x;
+  par2_b_primal_dev<RMAX>(a, d, k, sh);
+  __syncthreads();
+  par2_polar_dev(a.W, a.P, d, k, in_lds, sh);
+  __syncthreads();
+  par2_deltab_part_dev(a, d, k, sh);
+}
+// a.DeltaB: DeltaB of this iteration (read); a.DeltaBold: receives the new one
+template <int RRMAX>
+__global__ __launch_bounds__(kP2Threads) void par2_b_dual_fold_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
+  if (ctl->active == 0) return;
+  extern __shared__ double sh2[];         // Dn (RR) | Do (RR) | lane partials [64][RR + 1]
+  __shared__ double red[kP2Threads];
+  const int k = d.k0 + blockIdx.x, R = d.R, RR = R * R, W = RR + 1;
+  const int lane = threadIdx.x;
+  double* Dn = sh2;
+  double* Do = sh2 + RR;
+  double* lp = sh2 + 2 * RR;
+  {
+    double acc[RRMAX], sr = 0.0;
+#pragma unroll
+    for (int e = 0; e < RRMAX; ++e) acc[e] = 0.0;
+    for (int kk = d.k0 + lane; kk < d.k1; kk += kP2Threads) {
+      const double* pk = a.part + (int64_t)kk * RR;
+#pragma unroll
+      for (int e = 0; e < RRMAX; ++e)
+        if (e < RR) acc[e] += pk[e];
+      sr += a.rho[kk];
+    }
+#pragma unroll
+    for (int e = 0; e < RRMAX; ++e)
+      if (e < RR) lp[lane * W + e] = acc[e];
+    lp[lane * W + RR] = sr;
+    __syncthreads();
+    if (lane <= RR) {                      // lanes in order: the sum does not depend on scheduling
+      double tot = 0.0;
+      for (int q = 0; q < kP2Threads; ++q) tot += lp[q * W + lane];
+      red[lane] = tot;
+    }
+    __syncthreads();
+    if (lane < RR) {
+      const double dn = red[lane] / red[RR];                                    // :544
+      Dn[lane] = dn;
+      Do[lane] = a.DeltaB[lane];
+      if (blockIdx.x == 0) a.DeltaBold[lane] = dn;
+    }
+    __syncthreads();
+  }
+  const int64_t o = d.off[k];
+  const int Jk = (int)(d.off[k + 1] - o);
+  const int64_t base = o * R;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int e = threadIdx.x; e < Jk * R; e += blockDim.x) {
+    const int j = e % Jk, r = e / Jk;
+    double pd = 0.0, po = 0.0;
+    for (int q = 0; q < R; ++q) {
+      pd += a.P[base + j + Jk * q] * Dn[q + R * r];
+      po += a.Pold[base + j + Jk * q] * Do[q + R * r];
+    }
+    const double b = a.B[base + e];
+    const double m = a.mu[base + e] + b - pd;                                   // :546
+    a.mu[base + e] = m;
+    s0 += (b - pd) * (b - pd); s1 += b * b; s2 += (po - pd) * (po - pd); s3 += m * m;
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+  if (threadIdx.x == 0) {
+    double* nk = a.norms + (int64_t)k * 8;
+    nk[0] = s0; nk[1] = s1; nk[2] = s2; nk[3] = s3;
+  }
+}
+// closes the loop: residuals of the last iteration, and the final DeltaB / its predecessor into DeltaB / DeltaBold
+// (after c iterations the current one sits in buffer c & 1, buffer 0 being DeltaB)
+__global__ __launch_bounds__(kP2Threads) void par2_b_close_k(P2BArgs a, P2Dims d, AdmmCtl* ctl, P2Fold f) {
+  const int c = ctl->active ? f.max_inner : ctl->iters;      // iterations that ran (an earlier exit recorded its count)
+  (void)par2_b_head(a.norms, d, f, ctl, threadIdx.x == 0);
+  const int RR = d.R * d.R;
+  if ((c & 1) == 0) return;
+  for (int e = threadIdx.x; e < RR; e += kP2Threads) {
+    const double cur = a.DeltaBold[e], old = a.DeltaB[e];
+    a.DeltaB[e] = cur; a.DeltaBold[e] = old;
+  }
+}
+
+bool par2_b_loop_folded_ok(const P2Dims& d, bool constrained, bool sharded) {
+  static const bool off = getenv("AOADMM_NO_PAR2_FOLD") != nullptr;           // development switch
+  return !off && !constrained && !sharded && d.R <= 8;
+}
+
+void par2_b_loop_folded(const P2BArgs& a0, const P2Dims& d, AdmmCtl* ctl, int max_inner, double tpc, double tpz, double tdc,
+                        double tdz, hipStream_t s) {
+  AO_REQUIRE(par2_b_loop_folded_ok(d, a0.use_constr != 0, false), "par2_b_loop_folded: not applicable");
+  const int RR = d.R * d.R;
+  const size_t rr = (size_t)RR * sizeof(double);
+  const unsigned nk = (unsigned)(d.k1 - d.k0);
+  const size_t wl = (size_t)d.Jmax * d.R * sizeof(double);
+  const int in_lds = rr + wl <= 48 * 1024;
+  const size_t lds = std::max<size_t>(std::max<size_t>(2 * rr, rr + (in_lds ? wl : 0)), 64 * sizeof(double));
+  const size_t lds2 = (size_t)(2 * RR + kP2Threads * (RR + 1)) * sizeof(double);
+  P2Fold f{0, max_inner, tpc, tpz, tdc, tdz};
+  for (int it = 0; it < max_inner; ++it) {
+    P2BArgs a = a0;
+    a.DeltaB = (it & 1) ? a0.DeltaBold : a0.DeltaB;
+    a.DeltaBold = (it & 1) ? a0.DeltaB : a0.DeltaBold;
+    f.it = it;
+    if (d.R <= 4) par2_b_slab_fold_k<4><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds, f);
+    else par2_b_slab_fold_k<8><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds, f);
+    AO_KERNEL_CHECK();
+    if (RR <= 16) par2_b_dual_fold_k<16><<<nk, kP2Threads, lds2, s>>>(a, d, ctl);
+    else par2_b_dual_fold_k<64><<<nk, kP2Threads, lds2, s>>>(a, d, ctl);
+    AO_KERNEL_CHECK();
+  }
+  f.it = max_inner;
+  par2_b_close_k<<<1, kP2Threads, 0, s>>>(a0, d, ctl, f);
+  AO_KERNEL_CHECK();
+}
+
 void par2_b_iteration(const P2BArgs& a, const P2Dims& d, const AdmmCtl* ctl, hipStream_t s, double* psum,
                       const P2AllReduce& allreduce) {
   const size_t rr = (size_t)d.R * d.R * sizeof(double);

@@ -181,6 +181,13 @@ void Engine::par2_update_B(int m, const aoadmm_options& opt, int iter) {
   const P2AllReduce ar = [this](double* buf, int64_t n) { allreduce(buf, n); };
   double* psum = b.slab_sharded ? b.psum.d() : nullptr;
   double* part4 = b.slab_sharded ? b.psum.d() + (int64_t)b.R * b.R + 8 : nullptr;
+  if (par2_b_loop_folded_ok(d, constr, b.slab_sharded)) {
+    par2_b_loop_folded(a, d, ctl, opt.MaxInnerIters, opt.innerRelPrTol_coupl, opt.innerRelPrTol_constr,
+                       opt.innerRelDualTol_coupl, opt.innerRelDualTol_constr, stream_);
+    par2_gram(mi.fac.d(), d, b.GB.d(), stream_);                                         // :216-218
+    mi.version++;
+    return;
+  }
   for (int it = 0; it < opt.MaxInnerIters; ++it) {
     par2_b_iteration(a, d, ctl, stream_, psum, ar);
     if (constr)
