@@ -480,7 +480,7 @@ int aoadmm_op_mttkrp(aoadmm_ctx* ctx, const double* X, int ndims, const int64_t*
     DevBuf o;
     o.alloc((size_t)dims[n] * R * sizeof(double));
     // host in / host out on ONE engine with the whole tensor: no collective, whatever communicator the engine is in
-    e.block_mttkrp(blk, n, refs, R, 1.0, o.d(), dims[n], false, nullptr, 0, false);
+    e.block_mttkrp(blk, n, refs, R, 1.0, o.d(), dims[n], false, nullptr, 0, false, true);
     d2h(out, o, dims[n] * R, e.stream());
   });
 }

@@ -76,4 +76,20 @@ void launch_reduce_outer(const void* T, int tprec, int nchunk, int64_t trows, in
 void launch_t_to_colmajor(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int R, double scale,
                           double* out, int64_t ldOut, hipStream_t s);
 
+// A whole MTTKRP of a tiny block in one launch (contract.hip small_mttkrp_k): out(n, r) = scale * sum_{a,b}
+// X[n*sn + a*sa + b*sb] * Fa(a, r) * Fb(b, r).  Fb null with Nb = 1: matrices.
+constexpr int64_t kSmallMttkrpElems = (int64_t)1 << 19;
+struct SmallMttkrp {
+  const void* X;
+  int64_t sn, sa, sb;        // element strides of the target mode and of the two other modes
+  int Na, Nb, R;
+  const double *Fa, *Fb;     // column-major factors of the other modes
+  int64_t lda, ldb;
+  double scale;
+  double* out;
+  int64_t ldOut;
+};
+bool small_mttkrp_ok(int64_t elems, int nd, const int64_t* dims, int R);
+void small_mttkrp(const SmallMttkrp& a, int prec, int64_t rows, hipStream_t s);
+
 }  // namespace aoadmm

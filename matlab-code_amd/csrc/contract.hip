@@ -21,6 +21,7 @@
 //      issues 32 columns of matrix work per entry and ran 5.8 ms per 2000^3 pass against
 //      5.2 ms for 16 MFMA columns + 4 on the vector pipe.)
 #include "contract.h"
+#include "device_utils.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -1107,6 +1108,71 @@ void launch_reduce_outer(const void* T, int tprec, int nchunk, int64_t trows, in
   }
   AO_KERNEL_CHECK();
   reduce_outer_fin<<<(unsigned)cdiv(A * R, 256), 256, 0, s>>>(scratch, SB, A, R, scale, out, ldOut, rowmajor_out);
+  AO_KERNEL_CHECK();
+}
+
+// ---------------------------------------------------------------------------
+// Tiny blocks (the example scripts' 50 x 30 x 40 tensors and 50 x 70 matrices): a whole MTTKRP (:97) in ONE launch.
+// The matrix-core path needs three (factor fragments, partial contraction, reduction over T), each of them 3-5 us of
+// latency for microseconds of work.  One workgroup per output row n: the threads walk the (a, b) pairs of the two
+// other modes, the factors of those modes sit in LDS, R accumulators per thread, one workgroup reduction at the end
+// (fixed order).  Accumulation in fp64 whatever the tensor's precision.
+// ---------------------------------------------------------------------------
+template <typename TT, int RMAX>
+__global__ __launch_bounds__(256) void small_mttkrp_k(SmallMttkrp a) {
+  extern __shared__ double sf[];                     // Fa [Na][R] | Fb [Nb][R] | red [4][RMAX]
+  const int R = a.R, Na = a.Na, Nb = a.Nb;
+  double* fa = sf;
+  double* fb = sf + (size_t)Na * R;
+  double* red = fb + (size_t)(Nb > 0 ? Nb : 1) * R;
+  for (int e = threadIdx.x; e < Na * R; e += 256) { const int i = e / R, r = e - i * R; fa[e] = a.Fa[i + a.lda * r]; }
+  for (int e = threadIdx.x; e < Nb * R; e += 256) { const int i = e / R, r = e - i * R; fb[e] = a.Fb ? a.Fb[i + a.ldb * r] : 1.0; }
+  __syncthreads();
+  const TT* X = reinterpret_cast<const TT*>(a.X) + (int64_t)blockIdx.x * a.sn;
+  double acc[RMAX];
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) acc[r] = 0.0;
+  const int npairs = Na * Nb;
+  for (int p = threadIdx.x; p < npairs; p += 256) {
+    const int ia = p % Na, ib = p / Na;
+    const double x = (double)X[(int64_t)ia * a.sa + (int64_t)ib * a.sb];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r)
+      if (r < R) acc[r] += x * (fa[ia * R + r] * fb[ib * R + r]);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    const double v = wave_sum(acc[r]);
+    if (lane == 0) red[w * RMAX + r] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < R) {
+    const int r = threadIdx.x;
+    const double tot = (red[r] + red[RMAX + r]) + (red[2 * RMAX + r] + red[3 * RMAX + r]);
+    a.out[blockIdx.x + a.ldOut * r] = a.scale * tot;
+  }
+}
+
+bool small_mttkrp_ok(int64_t elems, int nd, const int64_t* dims, int R) {
+  // switch read on every call (not cached): the test suite runs the solver tests both ways in one process, so that
+  // the tensor-pass kernels and the partial-contraction cache stay covered at the sizes the oracle can follow
+  const bool off = getenv("AOADMM_NO_SMALL_MTTKRP") != nullptr;
+  if (off || elems > kSmallMttkrpElems || !(nd == 2 || nd == 3) || R > 16) return false;
+  int64_t sum = 0;                                   // the factors of the two other modes sit in LDS, whatever the target
+  for (int i = 0; i < nd; ++i) sum += dims[i];
+  return (size_t)(sum * R + 64) * sizeof(double) <= 40 * 1024;
+}
+
+void small_mttkrp(const SmallMttkrp& a, int prec, int64_t rows, hipStream_t s) {
+  AO_REQUIRE(a.R >= 1 && a.R <= 16 && rows >= 1 && a.Na >= 1 && a.Nb >= 1, "small_mttkrp: bad sizes");
+  const int rmax = a.R <= 4 ? 4 : (a.R <= 8 ? 8 : 16);
+  const size_t lds = ((size_t)(a.Na + a.Nb) * a.R + 4 * rmax) * sizeof(double);
+  AO_REQUIRE(lds <= 48 * 1024, "small_mttkrp: factors do not fit LDS");
+#define AO_SM(TT, RM) small_mttkrp_k<TT, RM><<<(unsigned)rows, 256, lds, s>>>(a)
+  if (prec == AOADMM_PREC_F32) { if (rmax == 4) AO_SM(float, 4); else if (rmax == 8) AO_SM(float, 8); else AO_SM(float, 16); }
+  else { if (rmax == 4) AO_SM(double, 4); else if (rmax == 8) AO_SM(double, 8); else AO_SM(double, 16); }
+#undef AO_SM
   AO_KERNEL_CHECK();
 }
 

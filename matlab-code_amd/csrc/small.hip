@@ -81,7 +81,9 @@ void gemm_small(double* out, int64_t ldo, const double* A, int64_t lda, const do
 // ---------------------------------------------------------------------------
 // A'B with fixed summation order: block b sums rows [b*rpb, (b+1)*rpb) -> ws[b][K*N]; then one block adds
 static constexpr int kAtbRows = 48;   // rows per block, staged through LDS
+static constexpr int kAtbOneBlockRows = 256;   // up to here one block walks all tiles and writes the result itself
 static int atb_blocks(int64_t I) {
+  if (I <= kAtbOneBlockRows) return 1;
   int64_t nb = cdiv(I, kAtbRows);
   if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
@@ -92,7 +94,7 @@ size_t atb_ws_bytes(int64_t I, int K, int N) { return (size_t)atb_blocks(I) * K 
 // block b owns rows [b*rpb, (b+1)*rpb): tiles of 64 rows of A and B are staged in LDS (coalesced
 // column reads), every thread accumulates its (k,n) outputs over the tile in a fixed order
 __global__ void atb_part_k(const double* A, int64_t lda, const double* B, int64_t ldb, int64_t I, int K, int N,
-                           double* ws, const AdmmCtl* ctl, double* At, LoopEnd le) {
+                           double* ws /* a single block: the result itself */, const AdmmCtl* ctl, double* At, LoopEnd le) {
   CTL_GUARD(ctl);
   if (le.ctl != nullptr && blockIdx.x == 0 && threadIdx.x < 64) loop_end_eval(le);   // first wave of block 0
   extern __shared__ double tile[];           // [kAtbRows][K] then [kAtbRows][N], row-major, padded by 1
@@ -165,8 +167,9 @@ void atb_small(double* out, const double* A, int64_t lda, const double* B, int64
                int K, int N, double* ws, const AdmmCtl* ctl, hipStream_t s, double* At_rowmajor, const LoopEnd* close) {
   const int nb = atb_blocks(I);
   const size_t sh = (size_t)kAtbRows * (K + N + 2) * sizeof(double);
-  atb_part_k<<<nb, 256, sh, s>>>(A, lda, B, ldb, I, K, N, ws, ctl, At_rowmajor, close ? *close : LoopEnd());
+  atb_part_k<<<nb, 256, sh, s>>>(A, lda, B, ldb, I, K, N, nb == 1 ? out : ws, ctl, At_rowmajor, close ? *close : LoopEnd());
   AO_KERNEL_CHECK();
+  if (nb == 1) return;                               // short matrices: one launch
   atb_fin_k<<<(unsigned)cdiv(K * N, 32), 256, 0, s>>>(out, ws, nb, K * N, ctl);
   AO_KERNEL_CHECK();
 }

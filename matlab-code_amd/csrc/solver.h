@@ -208,6 +208,8 @@ class Engine {
   void set_progress(aoadmm_progress_fn fn, void* user, int every) { progress_fn_ = fn; progress_user_ = user; progress_every_ = every; }
   void par2_gather_slabs(TensorInfo& t);
   bool sharded() const { return comm_ != nullptr || local_ != nullptr; }
+  // tiny unsharded block: MTTKRP by the one-launch kernel instead of contraction pass + reduction
+  bool small_direct(const CpBlock& b, int R) const { return !sharded() && small_mttkrp_ok(b.X.elems_padded(), b.nd, b.dims, R); }
   int rank() const { return rank_; }
   int world() const { return world_; }
 
@@ -227,8 +229,11 @@ class Engine {
   bool prefetch_next_contraction(const aoadmm_options& opt);   // true: a tensor pass was enqueued
   // `collective` = false: the block holds the whole tensor and the result is complete on this engine (op-level
   // entry on an engine that happens to belong to a communicator)
+  // `tensor_pass` = true: always the tensor-pass kernels, also for blocks small enough for the one-launch kernel
+  // (the op-level entries, so that their parity tests exercise the pass kernels at every size)
   void block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
-                    int64_t ldOut, bool use_cache, const int* update_seq, int nseq, bool collective = true);
+                    int64_t ldOut, bool use_cache, const int* update_seq, int nseq, bool collective = true,
+                    bool tensor_pass = false);
   // `full_array`: the caller's whole tensor when it holds one (lets a sharded engine take its mode-3 slab as well)
   void block_upload(CpBlock& b, int nd, const int64_t* dims, const double* host, int prec, int64_t row0,
                     int64_t local_rows, const double* full_array = nullptr);

@@ -758,7 +758,7 @@ void Engine::em_pass_enqueue(int p, int update, bool fuse_next_pass) {
   FactorRef facs[8];
   static const bool no_fuse = getenv("AOADMM_NO_EM_FUSE") != nullptr;       // development switch (tools/time_em.py)
   if (fuse_next_pass && update && b.nd == 3 && !no_fuse && em_cp_can_fuse(a, b.X.prec) && b.dims[1] <= 65535 &&
-      b.dims[2] <= 65535) {
+      b.dims[2] <= 65535 && !small_direct(b, a.R)) {
     for (int i = 0; i < t.nmodes; ++i) facs[i] = factor_ref(modes_[t.modes[i]]);
     const std::vector<int> seq = update_sequence(p);
     const int pos0 = seq.empty() ? 0 : seq[0];
@@ -1122,7 +1122,7 @@ bool Engine::prefetch_next_contraction(const aoadmm_options& opt) {
         const ModeInfo& mi = modes_[m];
         if (mi.coupling != cid || mi.tensor != p) continue;
         TensorInfo& t = tensors_[p];                      // first mode the next iteration updates
-        if (t.par2 || t.blk.nd != 3) return false;
+        if (t.par2 || t.blk.nd != 3 || small_direct(t.blk, mi.R)) return false;
         FactorRef facs[8];
         for (int i = 0; i < t.nmodes; ++i) {
           const ModeInfo& o = modes_[t.modes[i]];
@@ -1138,7 +1138,8 @@ bool Engine::prefetch_next_contraction(const aoadmm_options& opt) {
 }
 
 void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
-                          int64_t ldOut, bool use_cache, const int* update_seq, int nseq, bool collective) {
+                          int64_t ldOut, bool use_cache, const int* update_seq, int nseq, bool collective,
+                          bool tensor_pass) {
   AO_REQUIRE(b.has_data, "tensor has no data");
   AO_REQUIRE(pos >= 0 && pos < b.nd, "mttkrp: mode %d out of range", pos);
   const int prec = b.X.prec;
@@ -1154,6 +1155,22 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
   }
   const double* F0 = facs[0].p + (sharded ? b.row0 : 0);     // local rows of the first factor
 
+  if (!tensor_pass && small_direct(b, R)) {
+    // tiny block: the whole MTTKRP in one launch (contract.hip small_mttkrp_k), no partial-contraction cache
+    const int64_t J = b.dims[1], K = b.nd == 3 ? b.dims[2] : 1;
+    const int64_t st[3] = {1, Ip, Ip * J};
+    const int64_t ext[3] = {I, J, K};
+    int ia = pos == 0 ? 1 : 0, ib = pos == 2 ? 1 : 2;
+    SmallMttkrp sm;
+    sm.X = b.X.data.p;
+    sm.sn = st[pos]; sm.sa = st[ia]; sm.Na = (int)ext[ia];
+    sm.Fa = facs[ia].p; sm.lda = facs[ia].ld;
+    if (b.nd == 3) { sm.sb = st[ib]; sm.Nb = (int)ext[ib]; sm.Fb = facs[ib].p; sm.ldb = facs[ib].ld; }
+    else { sm.sb = 0; sm.Nb = 1; sm.Fb = nullptr; sm.ldb = 0; }
+    sm.R = R; sm.scale = scale; sm.out = out; sm.ldOut = ldOut;
+    small_mttkrp(sm, prec, ext[pos], stream_);
+    return;
+  }
   if (b.nd == 2) {
     const int64_t J = b.dims[1];
     if (pos == 0) {
@@ -3069,7 +3086,7 @@ void Engine::resident_mttkrp(int p, int pos, double* out_host, float* ms) {
   AO_HIP(hipEventCreate(&e0)); AO_HIP(hipEventCreate(&e1));
   AO_HIP(hipEventRecord(e0, stream_));
   t.blk.cached_mode = -1;                              // a full MTTKRP: tensor pass + reduction, on the pass's resident copy
-  block_mttkrp(t.blk, pos, facs, mi.R, 1.0, mi.A.d(), mi.rows, true, nullptr, 0);
+  block_mttkrp(t.blk, pos, facs, mi.R, 1.0, mi.A.d(), mi.rows, true, nullptr, 0, true, true);
   t.blk.cached_mode = -1;                              // the solver's own factors may differ from what this pass used
   AO_HIP(hipEventRecord(e1, stream_));
   AO_HIP(hipEventSynchronize(e1));

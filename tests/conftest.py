@@ -24,3 +24,12 @@ def eng(pkg):
     e = pkg.Engine(0)
     yield e
     e.close()
+
+
+@pytest.fixture
+def tensor_passes():
+    """Solver MTTKRPs through the tensor-pass kernels (partial contraction + reduction, dimension-tree cache) even for
+    blocks small enough for the one-launch kernel (contract.hip small_mttkrp_k); the library reads the switch per call."""
+    os.environ['AOADMM_NO_SMALL_MTTKRP'] = '1'
+    yield
+    os.environ.pop('AOADMM_NO_SMALL_MTTKRP', None)

@@ -137,7 +137,7 @@ def test_config5_2000cube_mttkrp_inner_product_identity(pkg, eng):
     pkg.build_model(eng, small, 'f64')
 
 
-def test_dimension_tree_reuse_changes_nothing(pkg, eng):
+def test_dimension_tree_reuse_changes_nothing(pkg, eng, tensor_passes):
     """Cached partial contractions (2 tensor reads / iteration) give the same factors as recomputing every
     mode's contraction (3 reads).  With the cache, mode 1 is sometimes finished from the middle-mode
     contraction instead of the last-mode one, so sums differ in order only: 1e-12."""
@@ -156,7 +156,7 @@ def test_dimension_tree_reuse_changes_nothing(pkg, eng):
 
 
 @pytest.mark.parametrize('dims,R', [((48, 40, 36), 4), ((131, 37, 29), 20), ((200, 17, 23), 7), ((70, 64, 66), 33)])
-def test_fp32_leading_mode_contraction_path(pkg, eng, dims, R):
+def test_fp32_leading_mode_contraction_path(pkg, eng, dims, R, tensor_passes):
     """fp32 mode with the dimension tree uses the LDS-transposed leading-mode contraction (1.5 tensor reads per
     iteration); without it only the register-streaming kernels run.  Both must agree to fp32 accuracy and
     track the fp64 oracle (1e-4 after 6 iterations; 3e-5 between the two fp32 paths), including ragged tiles (I % 64 != 0, J*K % 128 != 0)."""

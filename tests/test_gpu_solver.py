@@ -2,6 +2,7 @@
 identical init struct, tolerances 0 => fixed iteration counts; bar = 1e-8 relative Frobenius
 on every factor matrix (BASELINE.json north_star)."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -10,6 +11,16 @@ from oracle import aoadmm as OA
 from helpers import cp_cp_exact_model, cp_model, options, rel_fro, script3_model
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=['one-launch', 'tensor-pass'])
+def mttkrp_path(request):
+    """Every solver test runs twice: tiny blocks take the one-launch MTTKRP kernel by default, which would leave the
+    tensor-pass kernels, the partial-contraction cache and the fused EM contraction untested at oracle-sized shapes."""
+    if request.param == 'tensor-pass':
+        os.environ['AOADMM_NO_SMALL_MTTKRP'] = '1'
+    yield
+    os.environ.pop('AOADMM_NO_SMALL_MTTKRP', None)
 TOL = 1e-8
 
 
