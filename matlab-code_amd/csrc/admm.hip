@@ -1339,13 +1339,17 @@ __device__ __forceinline__ void wg_sum(double (&v)[NV], double* red /* [NW][NV] 
   __syncthreads();
 }
 
-template <int RMAX, int NT>
+// SOLVE: 0 = inv(L*L') shared, 1 = L shared, 2 = one factor per row.  For 0 and 1 the matrix sits in LDS as an
+// RMAX x RMAX block padded with zeros (reciprocal diagonal 0 beyond the rank) and the row operands are padded with
+// zeros, so the solve is straight-line code without rank tests; a padded column stays exactly zero.
+template <int RMAX, int NT, int SOLVE>
 __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
   constexpr int NW = NT / 64;
-  extern __shared__ double lds[];                    // M[RMAX*RMAX] | red[NW][max(RMAX,4)] | fsh[rows][RP] (Gram)
+  extern __shared__ double lds[];                    // M[RMAX*RMAX] | invd[RMAX] | red[NW][max(RMAX,4)] | fsh[rows][RP] (Gram)
   constexpr int NRED = RMAX > 4 ? RMAX : 4;
   double* Msh = lds;
-  double* red = lds + RMAX * RMAX;
+  double* invd = lds + RMAX * RMAX;
+  double* red = invd + RMAX;
   double* fsh = red + NW * NRED;
   AdmmCtl* ctl = a.ctl;
   if (!a.reset && ctl->active == 0) return;          // a failed factorisation (sys_build) leaves the state untouched
@@ -1357,14 +1361,20 @@ __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
   double av[RMAX], z[RMAX], mu[RMAX], x[RMAX];
 #pragma unroll
   for (int c = 0; c < RMAX; ++c) {
-    const int64_t o = i + rows * (c < R ? c : 0);
-    av[c] = a.A[o]; z[c] = a.Z[o]; mu[c] = a.mu[o];
+    const bool ok = c < R;
+    const int64_t o = i + rows * (ok ? c : 0);
+    av[c] = ok ? a.A[o] : 0.0; z[c] = ok ? a.Z[o] : 0.0; mu[c] = ok ? a.mu[o] : 0.0;
     x[c] = 0.0;
   }
-  const double* Msrc = a.Binv ? a.Binv : a.L;
-  if (!a.per_row)
-    for (int e = t; e < R * R; e += NT) Msh[e] = Msrc[e];
-  const double rho = a.per_row ? a.rho[i] : a.rho[0];
+  if (SOLVE != 2) {
+    const double* Msrc = SOLVE == 0 ? a.Binv : a.L;
+    for (int e = t; e < RMAX * RMAX; e += NT) {
+      const int r = e % RMAX, c = e / RMAX;
+      Msh[e] = (r < R && c < R) ? Msrc[r + R * c] : 0.0;
+    }
+    if (t < RMAX) invd[t] = (SOLVE == 1 && t < R) ? 1.0 / Msrc[t + R * t] : 0.0;
+  }
+  const double rho = SOLVE == 2 ? a.rho[i] : a.rho[0];
   const double rho_prox = a.rho_prox[0];             // max(rho) of a PARAFAC2 C mode (:1423-1424); rho otherwise
   const double rh = rho / 2;
   const ElemProx ep = elem_prox_of(a.ptype, a.p0, a.p1, rho_prox);
@@ -1375,13 +1385,13 @@ __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
   double pr = 0.0, du = 0.0;
   int it = 0;
   for (;;) {
-    // the system matrix is re-read (LDS / L1) every iteration: hoisted out of the loop its R*R entries alone would
-    // take more registers than the row operands (compiler barrier)
+    // the system matrix is re-read (LDS / L1) every iteration: hoisted out of the loop its entries alone would take
+    // more registers than the row operands (compiler barrier)
     asm volatile("" ::: "memory");
     // A_inner = A + rho/2*(Z - mu) (:608) and the solve (:609)
 #pragma unroll
-    for (int c = 0; c < RMAX; ++c) x[c] = c < R ? av[c] + rh * (z[c] - mu[c]) : 0.0;
-    if (a.per_row) {
+    for (int c = 0; c < RMAX; ++c) x[c] = av[c] + rh * (z[c] - mu[c]);
+    if (SOLVE == 2) {
       const double* Lk = a.L + i * (int64_t)R * R;
 #pragma unroll
       for (int r = 0; r < RMAX; ++r) {
@@ -1403,22 +1413,32 @@ __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
           x[r] = v / Lk[r + R * r];
         }
       }
-    } else if (a.Binv) {
+    } else if (SOLVE == 0) {
       double y[RMAX];
 #pragma unroll
       for (int c = 0; c < RMAX; ++c) {
         double acc = 0.0;
-        if (c < R) {
 #pragma unroll
-          for (int q = 0; q < RMAX; ++q)
-            if (q < R) acc += x[q] * Msh[q + R * c];
-        }
+        for (int q = 0; q < RMAX; ++q) acc += x[q] * Msh[q + RMAX * c];
         y[c] = acc;
       }
 #pragma unroll
       for (int c = 0; c < RMAX; ++c) x[c] = y[c];
     } else {
-      row_solve_regs2<RMAX>(x, Msh, R);
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {               // x * inv(L*L'): forward, then backward substitution
+        double v = x[r];
+#pragma unroll
+        for (int q = 0; q < r; ++q) v -= Msh[r + RMAX * q] * x[q];
+        x[r] = v * invd[r];
+      }
+#pragma unroll
+      for (int r = RMAX - 1; r >= 0; --r) {
+        double v = x[r];
+#pragma unroll
+        for (int q = r + 1; q < RMAX; ++q) v -= Msh[q + RMAX * r] * x[q];
+        x[r] = v * invd[r];
+      }
     }
     // update_constraint (:1420-1429): Z = prox(fac + mu), mu += fac - Z
     double zn[RMAX];
@@ -1429,12 +1449,12 @@ __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
 #pragma unroll
       for (int c = 0; c < RMAX; ++c) {
         const double y = clampv ? fmax(zn[c], 0.0) : zn[c];
-        cs[c] = have && c < R ? y * y : 0.0;
+        cs[c] = have ? y * y : 0.0;
       }
       wg_sum<RMAX, NW>(cs, red);
 #pragma unroll
       for (int c = 0; c < RMAX; ++c) {
-        if (c >= R) continue;
+        if (c >= R) { zn[c] = 0.0; continue; }       // uniform
         const double nrm = sqrt(cs[c]);
         const double y = clampv ? fmax(zn[c], 0.0) : zn[c];
         if (a.ptype == AOADMM_C_NONNEG_L2_SPHERE) {
@@ -1473,19 +1493,19 @@ __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
       }
     } else if (a.ptype == AOADMM_C_SIMPLEX_ROW) {
       simplex_regs<RMAX>(zn, R, a.p0);
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) zn[c] = c < R ? zn[c] : 0.0;
     } else {
 #pragma unroll
-      for (int c = 0; c < RMAX; ++c) zn[c] = elem_prox(ep, zn[c]);
+      for (int c = 0; c < RMAX; ++c) zn[c] = c < R ? elem_prox(ep, zn[c]) : 0.0;
     }
     double sm[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int c = 0; c < RMAX; ++c) {
-      if (c < R) {
-        const double mn = mu[c] + x[c] - zn[c];
-        const double d = x[c] - zn[c], e = zn[c] - z[c];
-        if (have) { sm[0] += d * d; sm[1] += x[c] * x[c]; sm[2] += mn * mn; sm[3] += e * e; }
-        mu[c] = mn; z[c] = zn[c];
-      }
+      const double mn = mu[c] + x[c] - zn[c];
+      const double d = x[c] - zn[c], e = zn[c] - z[c];
+      if (have) { sm[0] += d * d; sm[1] += x[c] * x[c]; sm[2] += mn * mn; sm[3] += e * e; }
+      mu[c] = mn; z[c] = zn[c];
     }
     wg_sum<4, NW>(sm, red);
     pr = sqrt(sm[0]) / sqrt(sm[1]);                                          // :1085
@@ -1514,7 +1534,7 @@ __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
   if (have) {
 #pragma unroll
     for (int c = 0; c < RMAX; ++c) {
-      fsh[t * RP + c] = c < R ? x[c] : 0.0;
+      fsh[t * RP + c] = x[c];
       if (c < R && a.facT) a.facT[(int64_t)t * R + c] = x[c];
     }
   }
@@ -1527,14 +1547,14 @@ __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
     const int q = p + rem;
     double acc = 0.0;
     for (int64_t r0 = lane; r0 < rows; r0 += 64) acc += fsh[r0 * RP + p] * fsh[r0 * RP + q];
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    acc = wave_sum(acc);
     if (lane == 0) { a.gram[p + R * q] = acc; a.gram[q + R * p] = acc; }
   }
 }
 
 size_t admm_loop_wg_lds(int rmax, int nt, int64_t rows, bool gram) {
   const int nred = rmax > 4 ? rmax : 4;
-  return ((size_t)rmax * rmax + (size_t)(nt / 64) * nred + (gram ? (size_t)rows * (rmax | 1) : 0)) * sizeof(double);
+  return ((size_t)rmax * rmax + rmax + (size_t)(nt / 64) * nred + (gram ? (size_t)rows * (rmax | 1) : 0)) * sizeof(double);
 }
 
 bool admm_loop_wg_ok(int64_t rows, int R, int ptype, int max_inner) {
@@ -1547,13 +1567,17 @@ bool admm_loop_wg_ok(int64_t rows, int R, int ptype, int max_inner) {
 void admm_loop_wg(const WgLoopU& a, hipStream_t s) {
   AO_REQUIRE(admm_loop_wg_ok(a.rows, a.R, a.ptype, a.max_inner), "admm_loop_wg: mode too large for the one-workgroup loop");
   const bool gram = a.gram != nullptr;
-  auto go = [&](auto kern, int rmax) {
-    const size_t lds = admm_loop_wg_lds(rmax, kWgLoopRows, a.rows, gram);
-    kern<<<1, kWgLoopRows, lds, s>>>(a);
+  const int solve = a.per_row ? 2 : (a.Binv ? 0 : 1);
+  auto go = [&](auto rm) {
+    constexpr int RM = decltype(rm)::value;
+    const size_t lds = admm_loop_wg_lds(RM, kWgLoopRows, a.rows, gram);
+    if (solve == 0) admm_loop_wg_k<RM, kWgLoopRows, 0><<<1, kWgLoopRows, lds, s>>>(a);
+    else if (solve == 1) admm_loop_wg_k<RM, kWgLoopRows, 1><<<1, kWgLoopRows, lds, s>>>(a);
+    else admm_loop_wg_k<RM, kWgLoopRows, 2><<<1, kWgLoopRows, lds, s>>>(a);
   };
-  if (a.R <= 4) go(admm_loop_wg_k<4, kWgLoopRows>, 4);
-  else if (a.R <= 8) go(admm_loop_wg_k<8, kWgLoopRows>, 8);
-  else go(admm_loop_wg_k<16, kWgLoopRows>, 16);
+  if (a.R <= 4) go(std::integral_constant<int, 4>());
+  else if (a.R <= 8) go(std::integral_constant<int, 8>());
+  else go(std::integral_constant<int, 16>());
   AO_KERNEL_CHECK();
 }
 

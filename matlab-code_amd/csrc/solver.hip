@@ -2051,40 +2051,44 @@ __global__ __launch_bounds__(256) void couple_loop_wg_k(WgLoopArgs a) {
 // loop and are stored once.  An inner iteration is then arithmetic plus one workgroup reduction, with no memory round
 // trip (the global-memory form re-reads its own stores from L2 several times per iteration: 25 us per iteration
 // against a few us here at 50 rows x 4 columns).
-template <int RMAX, int NM>
+// Everything is padded to RMAX with zeros -- the small matrices in LDS (L_j, H_j, L_AA as RMAX x RMAX blocks), the
+// reciprocal diagonals (0 beyond the rank) and the register rows -- so the loop body is straight-line code: a padded
+// column contributes exact zeros to every sum and is never stored.  (The first version tested `r < R` and `c < q` at
+// every step: ~5000 instructions, 700 of them branches, 10 us per inner iteration; PMC: 15 cycles per instruction on
+// the one wave per SIMD.)  T4: coupling type 4 (C = Delta*H), else type 0 (C = Delta).
+template <int RMAX, int NM, bool T4>
 __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
-  extern __shared__ double sh[];                      // LAA (q*q) | per mode: L (R*R), H (q*R)
+  constexpr int RR = RMAX * RMAX;
+  __shared__ double Lsh[NM][RR];                      // L_j, column-major with leading dimension RMAX
+  __shared__ double Hsh[NM][RR];                      // H_j(c, r) at c + RMAX*r
+  __shared__ double LAAsh[RR];
   __shared__ double red[4][8 * NM];
   __shared__ double invd[NM + 1][RMAX];               // reciprocal diagonals of L_j and of LAA: the substitutions multiply
   __shared__ int go;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int q = a.q, type = a.type;
+  const int q = a.q;
   const int64_t rows = a.rows;
   const int64_t i = t;
   const bool have = i < rows;
   const int64_t ic = have ? i : rows - 1;             // clamped: padding threads compute on a valid row, store nothing
-  int offL[NM], offH[NM];
-  {
-    int off = q * q;
-#pragma unroll
-    for (int j = 0; j < NM; ++j) { offL[j] = off; off += a.m[j].R * a.m[j].R; offH[j] = off; off += q * a.m[j].R; }
-    if (type == 4)
-      for (int e = t; e < q * q; e += 256) sh[e] = a.LAA[e];
+  for (int e = t; e < RR; e += 256) {
+    const int r = e % RMAX, c = e / RMAX;
+    LAAsh[e] = (T4 && r < q && c < q) ? a.LAA[r + q * c] : 0.0;
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
       const int R = a.m[j].R;
-      for (int e = t; e < R * R; e += 256) sh[offL[j] + e] = a.m[j].L[e];
-      if (type == 4)
-        for (int e = t; e < q * R; e += 256) sh[offH[j] + e] = a.m[j].H[e];
+      Lsh[j][e] = (r < R && c < R) ? a.m[j].L[r + R * c] : 0.0;
+      Hsh[j][e] = (T4 && r < q && c < R) ? a.m[j].H[r + q * c] : 0.0;
     }
   }
   __syncthreads();
   if (t < RMAX) {
 #pragma unroll
-    for (int j = 0; j < NM; ++j) invd[j][t] = t < a.m[j].R ? 1.0 / sh[offL[j] + t + a.m[j].R * t] : 0.0;
-    invd[NM][t] = (type == 4 && t < q) ? 1.0 / sh[t + q * t] : 0.0;
+    for (int j = 0; j < NM; ++j) invd[j][t] = t < a.m[j].R ? 1.0 / Lsh[j][t + RMAX * t] : 0.0;
+    invd[NM][t] = (T4 && t < q) ? 1.0 / LAAsh[t + RMAX * t] : 0.0;
   }
-  double d[RMAX], av[NM][RMAX], f[NM][RMAX], md[NM][RMAX], z[NM][RMAX], mu[NM][RMAX], zo[NM][RMAX], rh[NM], rho[NM];
+  double d[RMAX], av[NM][RMAX], f[NM][RMAX], md[NM][RMAX], z[NM][RMAX], mu[NM][RMAX], zo[NM][RMAX], rh[NM], rho[NM], cj[NM];
+  ElemProx ep[NM];
 #pragma unroll
   for (int c = 0; c < RMAX; ++c) d[c] = c < q ? a.Delta[ic + rows * c] : 0.0;
 #pragma unroll
@@ -2092,6 +2096,8 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
     const WgLoopMode& m = a.m[j];
     rho[j] = m.rho[0];
     rh[j] = rho[j] / 2;
+    cj[j] = T4 ? 0.0 : a.coefs[j];                    // rho_j / sum rho
+    ep[j] = elem_prox_of(m.ptype, m.p0, m.p1, rho[j]);
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
       const bool ok = r < m.R;
@@ -2122,48 +2128,37 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
       const WgLoopMode& m = a.m[j];
-      const int R = m.R;
-      const double* Lsh = sh + offL[j];
-      const double* Hsh = sh + offH[j];
       double x[RMAX];
 #pragma unroll
       for (int r = 0; r < RMAX; ++r) {
-        x[r] = 0.0;
-        if (r < R) {
-          double td;
-          if (type == 4) {                            // (Delta*H)(i,r)  (:925)
-            td = 0.0;
+        double td;
+        if (T4) {                                     // (Delta*H)(i,r)  (:925)
+          td = 0.0;
 #pragma unroll
-            for (int c = 0; c < RMAX; ++c)
-              if (c < q) td += d[c] * Hsh[c + q * r];
-          } else {
-            td = d[r];                                // :647
-          }
-          double v = av[j][r] + rh[j] * (td - md[j][r]);
-          if (m.constrained) v += rh[j] * (z[j][r] - mu[j][r]);
-          x[r] = v;
+          for (int c = 0; c < RMAX; ++c) td += d[c] * Hsh[j][c + RMAX * r];
+        } else {
+          td = d[r];                                  // :647
         }
+        double v = av[j][r] + rh[j] * (td - md[j][r]);
+        if (m.constrained) v += rh[j] * (z[j][r] - mu[j][r]);
+        x[r] = v;
       }
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r)                  // x * inv(L*L')  (:651, :929)
-        if (r < R) {
-          double v = x[r];
+      for (int r = 0; r < RMAX; ++r) {                // x * inv(L*L')  (:651, :929)
+        double v = x[r];
 #pragma unroll
-          for (int p = 0; p < RMAX; ++p)
-            if (p < r) v -= Lsh[r + R * p] * x[p];
-          x[r] = v * invd[j][r];
-        }
+        for (int p = 0; p < r; ++p) v -= Lsh[j][r + RMAX * p] * x[p];
+        x[r] = v * invd[j][r];
+      }
 #pragma unroll
-      for (int r = RMAX - 1; r >= 0; --r)
-        if (r < R) {
-          double v = x[r];
+      for (int r = RMAX - 1; r >= 0; --r) {
+        double v = x[r];
 #pragma unroll
-          for (int p = 0; p < RMAX; ++p)
-            if (p > r && p < R) v -= Lsh[p + R * r] * x[p];
-          x[r] = v * invd[j][r];
-        }
+        for (int p = r + 1; p < RMAX; ++p) v -= Lsh[j][p + RMAX * r] * x[p];
+        x[r] = v * invd[j][r];
+      }
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) f[j][r] = r < R ? x[r] : 0.0;
+      for (int r = 0; r < RMAX; ++r) f[j][r] = x[r];
     }
     // ---- Delta
     double bb[RMAX];
@@ -2171,76 +2166,63 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
     for (int c = 0; c < RMAX; ++c) bb[c] = 0.0;
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
-      const WgLoopMode& m = a.m[j];
-      if (type == 4) {
-        const double* Hj = sh + offH[j];
+      if (T4) {
 #pragma unroll
-        for (int c = 0; c < RMAX; ++c)
-          if (c < q) {
-            double acc = 0.0;
+        for (int c = 0; c < RMAX; ++c) {
+          double acc = 0.0;
 #pragma unroll
-            for (int r = 0; r < RMAX; ++r)
-              if (r < m.R) acc += (f[j][r] + md[j][r]) * Hj[c + q * r];
-            bb[c] = (j == 0 ? 0.0 : bb[c]) + rho[j] * acc;                         // :955
-          }
+          for (int r = 0; r < RMAX; ++r) acc += (f[j][r] + md[j][r]) * Hsh[j][c + RMAX * r];
+          bb[c] = (j == 0 ? 0.0 : bb[c]) + rho[j] * acc;                           // :955
+        }
       } else {
-        const double cj = a.coefs[j];                 // rho_j / sum rho
 #pragma unroll
-        for (int c = 0; c < RMAX; ++c)
-          if (c < q) {
-            const double v = cj * f[j][c] + cj * md[j][c];
-            bb[c] = j == 0 ? v : bb[c] + v;
-          }
+        for (int c = 0; c < RMAX; ++c) {
+          const double v = cj[j] * f[j][c] + cj[j] * md[j][c];
+          bb[c] = j == 0 ? v : bb[c] + v;
+        }
       }
     }
-    if (type == 4) {                                  // Delta(i,:) = bb * inv(LAA*LAA')
-      const double* Lsh = sh;
+    if (T4) {                                         // Delta(i,:) = bb * inv(LAA*LAA')
 #pragma unroll
-      for (int c = 0; c < RMAX; ++c)
-        if (c < q) {
-          double v = bb[c];
+      for (int c = 0; c < RMAX; ++c) {
+        double v = bb[c];
 #pragma unroll
-          for (int p = 0; p < RMAX; ++p)
-            if (p < c) v -= Lsh[c + q * p] * bb[p];
-          bb[c] = v * invd[NM][c];
-        }
+        for (int p = 0; p < c; ++p) v -= LAAsh[c + RMAX * p] * bb[p];
+        bb[c] = v * invd[NM][c];
+      }
 #pragma unroll
-      for (int c = RMAX - 1; c >= 0; --c)
-        if (c < q) {
-          double v = bb[c];
+      for (int c = RMAX - 1; c >= 0; --c) {
+        double v = bb[c];
 #pragma unroll
-          for (int p = 0; p < RMAX; ++p)
-            if (p > c && p < q) v -= Lsh[p + q * c] * bb[p];
-          bb[c] = v * invd[NM][c];
-        }
+        for (int p = c + 1; p < RMAX; ++p) v -= LAAsh[p + RMAX * c] * bb[p];
+        bb[c] = v * invd[NM][c];
+      }
     }
 #pragma unroll
     for (int c = 0; c < RMAX; ++c) {
+      const double nv = (T4 || c < q) ? bb[c] : 0.0;  // type 0: columns beyond q carry nothing
       dold[c] = d[c];
-      dd[c] = c < q ? bb[c] - d[c] : 0.0;
-      d[c] = c < q ? bb[c] : 0.0;
+      dd[c] = nv - d[c];
+      d[c] = nv;
     }
     // ---- coupling duals, constraints, residual sums
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
       const WgLoopMode& m = a.m[j];
       const int R = m.R;
-      const double* Hsh = sh + offH[j];
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r)
-        if (r < R) {
-          double td, tdd;
-          if (type == 4) {
-            td = 0.0; tdd = 0.0;
+      for (int r = 0; r < RMAX; ++r) {
+        double td, tdd;
+        if (T4) {
+          td = 0.0; tdd = 0.0;
 #pragma unroll
-            for (int c = 0; c < RMAX; ++c)
-              if (c < q) { td += d[c] * Hsh[c + q * r]; tdd += dd[c] * Hsh[c + q * r]; }
-          } else { td = d[r]; tdd = dd[r]; }
-          const double g = f[j][r] - td;
-          const double mm = md[j][r] + g;                                           // :679, :967
-          md[j][r] = mm;
-          if (have) { sums[j][4] += g * g; sums[j][5] += mm * mm; sums[j][6] += tdd * tdd; sums[j][7] += f[j][r] * f[j][r]; }
-        }
+          for (int c = 0; c < RMAX; ++c) { td += d[c] * Hsh[j][c + RMAX * r]; tdd += dd[c] * Hsh[j][c + RMAX * r]; }
+        } else { td = r < R ? d[r] : 0.0; tdd = r < R ? dd[r] : 0.0; }
+        const double g = f[j][r] - td;
+        const double mm = md[j][r] + g;                                             // :679, :967
+        md[j][r] = mm;
+        if (have) { sums[j][4] += g * g; sums[j][5] += mm * mm; sums[j][6] += tdd * tdd; sums[j][7] += f[j][r] * f[j][r]; }
+      }
       if (m.constrained) {                            // update_constraint (:1420-1429)
         double zn[RMAX];
 #pragma unroll
@@ -2249,20 +2231,19 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
           simplex_regs<RMAX>(zn, R, m.p0);
         } else {
 #pragma unroll
-          for (int r = 0; r < RMAX; ++r) zn[r] = prox_elem(m.ptype, zn[r], m.p0, m.p1, rho[j]);
+          for (int r = 0; r < RMAX; ++r) zn[r] = r < R ? elem_prox(ep[j], zn[r]) : 0.0;
         }
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r)
-          if (r < R) {
-            const double mn = mu[j][r] + f[j][r] - zn[r];
-            const double dz = zn[r] - zo[j][r];
-            if (have) {
-              sums[j][0] += (f[j][r] - zn[r]) * (f[j][r] - zn[r]); sums[j][1] += f[j][r] * f[j][r]; sums[j][2] += mn * mn;
-              sums[j][3] += dz * dz;
-            }
-            z[j][r] = zn[r];
-            mu[j][r] = mn;
+        for (int r = 0; r < RMAX; ++r) {
+          const double mn = mu[j][r] + f[j][r] - zn[r];
+          const double dz = zn[r] - zo[j][r];
+          if (have) {
+            sums[j][0] += (f[j][r] - zn[r]) * (f[j][r] - zn[r]); sums[j][1] += f[j][r] * f[j][r]; sums[j][2] += mn * mn;
+            sums[j][3] += dz * dz;
           }
+          z[j][r] = zn[r];
+          mu[j][r] = mn;
+        }
       } else if (have) {
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) sums[j][1] += f[j][r] * f[j][r];
@@ -2283,18 +2264,31 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
       a.m[t >> 3].slots[t & 7] = tot;
     }
     __syncthreads();
-    if (t == 0) {                                     // eval_res_ADMM_coupl_case0/4 + eval_res_ADMM_constr, while condition
+    // eval_res_ADMM_coupl_case0/4 + eval_res_ADMM_constr: the 4*NM ratios (two square roots and a division each, ~100
+    // dependent fp64 instructions) on 4*NM lanes side by side, then one lane adds them in mode order and decides --
+    // the whole workgroup waits for this
+    if (t < 4 * NM) {
+      const int j = t >> 2, which = t & 3;            // 0: primal coupling, 1: dual coupling, 2: primal constr., 3: dual constr.
+      const double* sj = &red[0][j * 8];
+      double v;
+      if (which == 0) v = sqrt(sj[4]) / sqrt(sj[7]);
+      else if (which == 2) v = sqrt(sj[0]) / sqrt(sj[1]);
+      else {
+        const double num = sqrt(which == 1 ? sj[6] : sj[3]), sc = sqrt(which == 1 ? sj[5] : sj[2]);
+        v = sc > 0 ? num / sc : num;
+      }
+      red[1][t] = v;
+    }
+    __syncthreads();
+    if (t == 0) {                                     // while condition
       double prc = 0, duc = 0, prz = 0, duz = 0;
       int nz = 0;
       for (int j = 0; j < NM; ++j) {
-        const double* sj = &red[0][j * 8];
-        prc += sqrt(sj[4]) / sqrt(sj[7]);
-        const double sc = sqrt(sj[5]);
-        duc += sc > 0 ? sqrt(sj[6]) / sc : sqrt(sj[6]);
+        prc += red[1][4 * j];
+        duc += red[1][4 * j + 1];
         if (a.m[j].constrained) {
-          prz += sqrt(sj[0]) / sqrt(sj[1]);
-          const double sz = sqrt(sj[2]);
-          duz += sz > 0 ? sqrt(sj[3]) / sz : sqrt(sj[3]);
+          prz += red[1][4 * j + 2];
+          duz += red[1][4 * j + 3];
           ++nz;
         }
       }
@@ -2441,9 +2435,10 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
           lds += (size_t)mi.R * mi.R + (size_t)q * mi.R;
         }
         if (rows <= 256 && rmax <= 8 && n <= 3) {     // one row per thread: the state stays in registers
-#define AO_WGR(RM, NMM) couple_loop_wg_regs_k<RM, NMM><<<1, 256, lds * sizeof(double), stream_>>>(wa)
-          if (rmax <= 4) { if (n == 1) AO_WGR(4, 1); else if (n == 2) AO_WGR(4, 2); else AO_WGR(4, 3); }
-          else { if (n == 1) AO_WGR(8, 1); else if (n == 2) AO_WGR(8, 2); else AO_WGR(8, 3); }
+#define AO_WGR(RM, NMM) { if (ty == 4) couple_loop_wg_regs_k<RM, NMM, true><<<1, 256, 0, stream_>>>(wa); \
+                          else couple_loop_wg_regs_k<RM, NMM, false><<<1, 256, 0, stream_>>>(wa); }
+          if (rmax <= 4) { if (n == 1) AO_WGR(4, 1) else if (n == 2) AO_WGR(4, 2) else AO_WGR(4, 3) }
+          else { if (n == 1) AO_WGR(8, 1) else if (n == 2) AO_WGR(8, 2) else AO_WGR(8, 3) }
 #undef AO_WGR
         } else {
           by_rmax([&](auto tag) { couple_loop_wg_k<decltype(tag)::value><<<1, 256, lds * sizeof(double), stream_>>>(wa); });
