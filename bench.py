@@ -220,6 +220,36 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # where the time outside the tensor passes goes: a few more iterations with the reductions over T timed as well
+    # (HIP events around them, switched on by the first kernel_stats(2) call; outside the timed region)
+    tail = None
+    try:
+        msr = C.c_double(); nlr = C.c_int64(); byr = C.c_double()
+        capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 2, 1, None, None, None, None))
+        capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 0, 1, None, None, None, None))
+        capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 1, 1, None, None, None, None))
+        nb = max(args.steps, 1)           # same length as the timed run: the solve's fixed cost weighs the same
+        eng.synchronize()
+        tb = time.perf_counter()
+        pkg.run_solver(eng, opts(nb), 3)
+        eng.synchronize()
+        tb = (time.perf_counter() - tb) / nb * 1e3
+        msp = C.c_double(); msp1 = C.c_double()
+        capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 2, 1, C.byref(msr), C.byref(nlr), C.byref(byr), None))
+        capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 0, 1, C.byref(msp), None, None, None))
+        capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 1, 1, C.byref(msp1), None, None, None))
+        red_ms = msr.value / nb
+        pass_ms = (msp.value + msp1.value) / nb
+        tail = {'iterations': nb, 'ms_per_step': tb, 'tensor_passes_ms': pass_ms, 't_reductions_ms': red_ms,
+                't_reductions_per_iter': nlr.value / nb,
+                't_reductions_GBps': (byr.value / (msr.value * 1e-3) / 1e9) if msr.value > 0 else None,
+                'replicated_small_kernels_ms': tb - pass_ms - red_ms,
+                'note': 'per rank; the reductions read the partial contraction T once each and shard with the passes; '
+                        'replicated_small_kernels_ms (system builds, ADMM inner loops, Gram matrices, objective) is what '
+                        'every rank repeats'}
+    except Exception as e:   # a report, never a reason to lose the headline number
+        tail = {'error': repr(e)}
+
     # bare mode-1 MTTKRP on the resident tensor (contraction + reduction), a few repetitions
     el = C.c_float()
     reps = []
@@ -285,6 +315,7 @@ def main():
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
             # everything that is not a tensor pass: T reductions, system builds, ADMM inner loops, Gram matrices
             'replicated_tail_ms': dt / args.steps * 1e3 - (launches + int(nl1.value)) / args.steps * avg_ms,
+            'tail_breakdown': tail,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': args.prec, 'data': 'synthetic',
             'config': {'workload': 'cfg5: %dx%dx%d R=%d CP, mode1 TV(0.001), modes2-3 nonneg, %s tensor + fp64 solve, '
                                    'MaxInnerIters=5, tol=0' % (I, J, K, R, args.prec),

@@ -235,7 +235,9 @@ int aoadmm_resident_mttkrp(aoadmm_ctx* ctx, int p, int tensor_mode, double* out_
                            float* elapsed_ms);
 /* device time (ms, HIP events on the library's stream around the kernel only), launch count, algorithmic
  * bytes and flops of a tensor-pass kernel since the last reset.  which = 0: register-streaming contraction
- * (contract_f32/f64, trailing modes); which = 1: LDS-transposed leading-mode contraction (contract_lead_f32) */
+ * (contract_f32/f64, trailing modes); which = 1: LDS-transposed leading-mode contraction (contract_lead_f32);
+ * which = 2: the reductions over the partial contraction T that finish an MTTKRP (bytes = size of T per reduction;
+ * timed only from the first call with which = 2 on, two more events per reduction) */
 int aoadmm_kernel_stats(aoadmm_ctx* ctx, int which, int reset, double* contract_ms, int64_t* contract_launches,
                         double* contract_bytes, double* contract_flops);
 

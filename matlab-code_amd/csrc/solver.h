@@ -283,8 +283,9 @@ class Engine {
   bool allow_xp_ = true;  // options.hip.no_permuted_copy
   DevBuf atbws_;
   DevBuf staging_;
-  KernelStats kstats_[2];   // [0] streaming contraction, [1] leading-mode contraction
+  KernelStats kstats_[3];   // [0] streaming contraction, [1] leading-mode contraction, [2] reductions over T
   bool profile_ = true;
+  bool profile_reductions_ = false;   // switched on by the first kernel_stats(2, ...) call: two more events per reduction
   ncclComm_t comm_ = nullptr;
   mutable std::mutex comm_mu_;          // comm_ / aborted_ against comm_abort() from another worker thread
   std::atomic<bool> aborted_{false};

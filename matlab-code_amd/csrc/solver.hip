@@ -935,7 +935,8 @@ void Engine::timed_contract(const void* X, int prec, const ContractPlan& pl, con
 }
 
 void Engine::kernel_stats(int which, int reset, double* ms, int64_t* launches, double* bytes, double* flops) {
-  AO_REQUIRE(which == 0 || which == 1, "kernel_stats: which must be 0 or 1");
+  AO_REQUIRE(which >= 0 && which <= 2, "kernel_stats: which must be 0, 1 or 2");
+  if (which == 2) profile_reductions_ = true;
   AO_HIP(hipSetDevice(device_));
   AO_HIP(hipStreamSynchronize(stream_));
   KernelStats& ks = kstats_[which];
@@ -1212,6 +1213,14 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
         AO_HIP(hipMemsetAsync(out + ldOut * r, 0, (size_t)K * sizeof(double), stream_));
       out_local = out + b.xp_k0;
     }
+    // the reduction over T is timed like the passes (kernel_stats slot 2): it reads all of T once
+    KernelStats& rs = kstats_[2];
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profile_ && profile_reductions_ && rs.pending.size() < 100000) {
+      AO_HIP(hipEventCreate(&e0));
+      AO_HIP(hipEventCreate(&e1));
+      AO_HIP(hipEventRecord(e0, stream_));
+    }
     if (pos == ia) {
       b.scratch.ensure(reduce_outer_scratch_bytes(An, Bn, R));
       b.ft.ensure(reduce_factor_scratch_bytes(Bn, R));
@@ -1223,6 +1232,12 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
       launch_reduce_inner(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, fac_p(ia), facs[ia].ld, scale, out_local,
                           ldOut, b.ft.d(), stream_, fac_pT(ia));
     }
+    if (e0) {
+      AO_HIP(hipEventRecord(e1, stream_));
+      rs.pending.emplace_back(e0, e1);
+    }
+    rs.launches++;
+    rs.bytes += (double)pl.t_bytes();
   } else {
     // N-way (N > 3): contract the last mode (the one before it when pos is last) on the matrix cores with all
     // leading modes merged into the unfolding row, then fold the remaining modes one at a time over T: trailing
