@@ -237,10 +237,7 @@ __device__ __forceinline__ void par2_b_primal_dev(const P2BArgs& a, const P2Dims
 // butterfly over the 64 lanes, which leaves bit-identical sums in every lane, so each lane derives the rotation
 // itself and nothing is exchanged through memory.  W_k is staged in LDS when it fits (in_lds), else rotated in place.
 static_assert(kP2Threads == 64, "par2_polar_dev reduces over exactly one wavefront");
-__device__ inline double wave_sum64(double v) {
-  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
-}
+__device__ inline double wave_sum64(double v) { return wave_sum(v); }   // DPP tree (device_utils.h), the same bits in every lane
 __device__ __forceinline__ void par2_polar_dev(double* W, double* P, const P2Dims& d, int k, int in_lds, double* Jr) {
   const int R = d.R, lane = threadIdx.x;  // Jr: R*R, then W_k (n*R) when in_lds
   const int64_t o = d.off[k];
