@@ -211,12 +211,7 @@ __global__ __launch_bounds__(kRowBlock) void admm_rows_k(FusedArgs a) {
     __syncthreads();                                  // rsh is rewritten at the top of the loop
   }
   if (a.fused) {
-    for (int off = 32; off > 0; off >>= 1) {        // fixed-order wave tree, then the four waves in order
-      s1 += __shfl_down(s1, off);
-      s2 += __shfl_down(s2, off);
-      s3 += __shfl_down(s3, off);
-      s4 += __shfl_down(s4, off);
-    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);   // fixed-order DPP tree
     if (lane == 0) { red[w * 4 + 0] = s1; red[w * 4 + 1] = s2; red[w * 4 + 2] = s3; red[w * 4 + 3] = s4; }
     __syncthreads();
     if (t < 4) {
@@ -300,10 +295,7 @@ __global__ __launch_bounds__(kSpecThreads) void admm_rows_mfma_k(FusedArgs a, Sp
 #pragma unroll
     for (int it = 1; it <= kSpecMaxInner; ++it) {
       double s0 = S[it - 1][0], s1 = S[it - 1][1], s2 = S[it - 1][2], s3 = S[it - 1][3];
-      for (int off = 32; off > 0; off >>= 1) {       // butterfly: every lane ends with the same total
-        s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off);
-        s2 += __shfl_xor(s2, off); s3 += __shfl_xor(s3, off);
-      }
+      s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);   // the same total in every lane
       if (!found && it <= a.max_inner) {
         pr = sqrt(s0) / sqrt(s1);                                            // :1085
         const double sc = sqrt(s2);
@@ -360,12 +352,7 @@ __global__ __launch_bounds__(kSpecThreads) void admm_rows_mfma_k(FusedArgs a, Sp
       }
     }
     if (!FINAL) {
-      for (int off = 32; off > 0; off >>= 1) {      // fixed-order wave tree
-        s1 += __shfl_down(s1, off);
-        s2 += __shfl_down(s2, off);
-        s3 += __shfl_down(s3, off);
-        s4 += __shfl_down(s4, off);
-      }
+      s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);   // fixed-order DPP tree
       if (lane == 0) {
         f64x4_t v = {s1, s2, s3, s4};
         *reinterpret_cast<f64x4_t*>(a.part + ((int64_t)it * nparts + blockIdx.x) * 4) = v;
@@ -492,12 +479,7 @@ __global__ __launch_bounds__(kRowThreads) void admm_rowL_k(FusedArgs a) {
     }
   }
   if (a.fused) {
-    for (int off = 32; off > 0; off >>= 1) {
-      s1 += __shfl_down(s1, off);
-      s2 += __shfl_down(s2, off);
-      s3 += __shfl_down(s3, off);
-      s4 += __shfl_down(s4, off);
-    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);   // fixed-order DPP tree
     if (threadIdx.x == 0) {
       double* pb = a.part + ((int64_t)(a.it & 1) * kMaxParts + blockIdx.x) * 4;
       pb[0] = s1; pb[1] = s2; pb[2] = s3; pb[3] = s4;
@@ -529,10 +511,7 @@ __global__ void dual_update_k(const double* fac, double* Z, double* mu, const do
     const double d = x - z, e = z - zo;
     s1 += d * d; s2 += x * x; s3 += mn * mn; s4 += e * e;
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off);
-    s3 += __shfl_down(s3, off); s4 += __shfl_down(s4, off);
-  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); s4 = wave_sum(s4);
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { red[0][w] = s1; red[1][w] = s2; red[2][w] = s3; red[3][w] = s4; }
   __syncthreads();
@@ -840,7 +819,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
   for (int i = c0; i < c1; ++i) loc += y[i];
   auto block_scan_d = [&](double v, double& total) {               // exclusive scan over threads, fixed order
     double inc = v;
-    for (int off = 1; off < 64; off <<= 1) { const double u = __shfl_up(inc, off); if (lane >= off) inc += u; }
+    inc = wave_scan_incl(inc);
     if (lane == 63) dsum[w] = inc;
     __syncthreads();
     double base = 0.0, all = 0.0;
@@ -881,7 +860,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
       int cnt = 0;
       for (int i = c0; i < c1; ++i) cnt += (i == 0 || J[i - 1] != 0) ? 1 : 0;
       int inc = cnt;
-      for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(inc, off); if (lane >= off) inc += u; }
+      inc = wave_scan_incl(inc);
       if (lane == 63) wsum[w] = inc;
       if (t == 0) { flag_merge = 0; flag_split = 0; }
       __syncthreads();
@@ -957,7 +936,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
         int cnt = 0;
         for (int i = c0; i < c1; ++i) cnt += (i == 0 || J[i - 1] != 0) ? 1 : 0;
         int inc = cnt;
-        for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(inc, off); if (lane >= off) inc += u; }
+        inc = wave_scan_incl(inc);
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
         int base = 0;
@@ -1018,7 +997,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     double v = q4[q];
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    v = wave_sum(v);
     if (lane == 0) q4sum[w][q] = v;
   }
   __syncthreads();

@@ -76,4 +76,25 @@ __device__ __forceinline__ double wave_sum(double v) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// Inclusive prefix sums over the 64 lanes of a FULL wavefront by the same DPP sequence (Hillis-Steele inside rows of 16,
+// then the row totals across rows).  All 64 lanes must be active.
+__device__ __forceinline__ double wave_scan_incl(double v) {
+  v += __builtin_amdgcn_update_dpp(0.0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0.0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0.0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0.0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0.0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0.0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+__device__ __forceinline__ int wave_scan_incl(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
 }  // namespace aoadmm

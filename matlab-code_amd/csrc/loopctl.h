@@ -2,6 +2,7 @@
 // Gram kernel that closes a loop (small.hip).
 #pragma once
 #include "small.h"
+#include "device_utils.h"
 
 namespace aoadmm {
 
@@ -17,10 +18,7 @@ __device__ __forceinline__ bool admm_continue(const double* part_prev, int npart
     const double* pb = part_prev + (int64_t)b * 4;
     s0 += pb[0]; s1 += pb[1]; s2 += pb[2]; s3 += pb[3];
   }
-  for (int off = 32; off > 0; off >>= 1) {       // butterfly: every lane ends with the same total
-    s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off);
-    s2 += __shfl_xor(s2, off); s3 += __shfl_xor(s3, off);
-  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);   // DPP tree: the same total in every lane
   const double pr = sqrt(s0) / sqrt(s1);                                   // :1085
   const double sc = sqrt(s2);
   const double du = sc > 0 ? sqrt(s3) / sc : sqrt(s3);                     // :1087-1092
