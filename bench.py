@@ -220,6 +220,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # factors after exactly warmup + steps iterations, for the fp32-vs-fp64 comparison below (the runs that follow
+    # iterate further)
+    fac32 = None
+    if world == 1 and args.prec == 'f32' and not args.no_drift:
+        fac32 = pkg.download_state(eng, Z, G0)['fac']
+
     # where the time outside the tensor passes goes: a few more iterations with the reductions over T timed as well
     # (HIP events around them, switched on by the first kernel_stats(2) call; outside the timed region)
     tail = None
@@ -267,9 +273,8 @@ def main():
     # same iterations: relative Frobenius gap of the factors.  Outside the timed region; the engines run one after the
     # other (96 GB, then 192 GB of HBM at 2000^3).
     drift = None
-    if world == 1 and args.prec == 'f32' and not args.no_drift:
+    if fac32 is not None:
         try:
-            fac32 = pkg.download_state(eng, Z, G0)['fac']
             eng.close()
             eng = pkg.Engine(local_rank)
             Z64 = build_Z(I, J, K, R, seed=0, noise=0.05)

@@ -32,9 +32,11 @@ find $OUT/pe -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/r02_em_
 rm -rf $OUT/pe
 cd $R
 timeout -k 10 600 python tools/time_configs.py > $OUT/r02_configs_timing.txt 2>&1
+echo "--- per-configuration scripts (slope between two solve lengths) ---" >> $OUT/r02_configs_timing.txt
+for c in 1 2 3 4; do timeout -k 10 300 python tools/time_cfg$c.py 2>&1 | grep -i "per outer iteration\|ms/iter" >> $OUT/r02_configs_timing.txt; done
 cat $OUT/r02_configs_timing.txt
 python3 -c "
 import json
 for f in ['r02_bench.json','r02_bench_f64.json']:
     d=json.loads(open('$OUT/'+f).read().strip().splitlines()[-1])
-    print(f, {k:d.get(k) for k in ['value','ms_per_step','mttkrp_mode1_ms','replicated_tail_ms']}, d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['roofline']['traffic'], d.get('fp32_drift'))"
+    print(f, {k:d.get(k) for k in ['value','ms_per_step','mttkrp_mode1_ms','replicated_tail_ms']}, d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['roofline']['traffic'], d.get('fp32_drift'), d.get('tail_breakdown'))"
