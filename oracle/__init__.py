@@ -29,4 +29,9 @@ Everything that *is* in the reference (`cmtf_fun_AOADMM.m`,
 line with `file:line` citations; the only reference-held data fixtures
 (`functions_for_example_scripts/noisy_dataset.mat`, `gnd_factors.mat`) are
 inputs, not expected outputs, and are used as inputs in `tests/`.
+
+`oracle/c/aoadmm_cpu.c` (+ `oracle/c_port.py`, `oracle/Makefile`) is a compiled C/OpenMP restatement of the same outer
+iteration for one dense 3-way CP block with constraints none / non-negativity / TV: the CPU baseline `bench.py` times
+beside the GPU number.  Same status (test infrastructure, parity unpinned); `tests/test_oracle_c.py` pins it to this
+package.
 """
