@@ -294,9 +294,10 @@ __global__ __launch_bounds__(kSpecThreads) void admm_rows_mfma_k(FusedArgs a, Sp
     bool found = false;
 #pragma unroll
     for (int it = 1; it <= kSpecMaxInner; ++it) {
+      if (it > a.max_inner) break;                     // uniform: iterations beyond the cap need no sums
       double s0 = S[it - 1][0], s1 = S[it - 1][1], s2 = S[it - 1][2], s3 = S[it - 1][3];
       s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);   // the same total in every lane
-      if (!found && it <= a.max_inner) {
+      if (!found) {
         pr = sqrt(s0) / sqrt(s1);                                            // :1085
         const double sc = sqrt(s2);
         du = sc > 0 ? sqrt(s3) / sc : sqrt(s3);                              // :1087-1092
