@@ -19,9 +19,18 @@ __global__ void par2_xkb_k(const double* X, const double* B, P2Dims d, double* T
   const double* Bk = B + o * d.R;
   for (int e = threadIdx.x; e < d.I * d.R; e += blockDim.x) {
     const int i = e % d.I, r = e / d.I;
-    double acc = 0.0;
-    for (int j = 0; j < Jk; ++j) acc += Xk[i + (int64_t)d.I * j] * Bk[j + Jk * r];
-    T1[(int64_t)k * d.I * d.R + e] = acc;
+    // four independent partial sums: the loads of four columns are in flight together (one accumulator made every
+    // step wait for its own load: J_k dependent L2 round trips, 15 us per launch at J_k ~ 90)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int j = 0;
+    for (; j + 3 < Jk; j += 4) {
+      const double x0 = Xk[i + (int64_t)d.I * j], x1 = Xk[i + (int64_t)d.I * (j + 1)];
+      const double x2 = Xk[i + (int64_t)d.I * (j + 2)], x3 = Xk[i + (int64_t)d.I * (j + 3)];
+      const double b0 = Bk[j + Jk * r], b1 = Bk[j + 1 + Jk * r], b2 = Bk[j + 2 + Jk * r], b3 = Bk[j + 3 + Jk * r];
+      a0 += x0 * b0; a1 += x1 * b1; a2 += x2 * b2; a3 += x3 * b3;
+    }
+    for (; j < Jk; ++j) a0 += Xk[i + (int64_t)d.I * j] * Bk[j + Jk * r];
+    T1[(int64_t)k * d.I * d.R + e] = (a0 + a1) + (a2 + a3);
   }
 }
 void par2_xkb(const double* X, const double* B, const P2Dims& d, double* T1, hipStream_t s) {
@@ -36,9 +45,14 @@ __global__ void par2_gram_k(const double* B, P2Dims d, double* GB) {
   const double* Bk = B + o * d.R;
   for (int e = threadIdx.x; e < d.R * d.R; e += blockDim.x) {
     const int r = e % d.R, q = e / d.R;
-    double acc = 0.0;
-    for (int j = 0; j < Jk; ++j) acc += Bk[j + Jk * r] * Bk[j + Jk * q];
-    GB[(int64_t)k * d.R * d.R + e] = acc;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // independent partial sums: four pairs of loads in flight
+    int j = 0;
+    for (; j + 3 < Jk; j += 4) {
+      a0 += Bk[j + Jk * r] * Bk[j + Jk * q]; a1 += Bk[j + 1 + Jk * r] * Bk[j + 1 + Jk * q];
+      a2 += Bk[j + 2 + Jk * r] * Bk[j + 2 + Jk * q]; a3 += Bk[j + 3 + Jk * r] * Bk[j + 3 + Jk * q];
+    }
+    for (; j < Jk; ++j) a0 += Bk[j + Jk * r] * Bk[j + Jk * q];
+    GB[(int64_t)k * d.R * d.R + e] = (a0 + a1) + (a2 + a3);
   }
 }
 void par2_gram(const double* B, const P2Dims& d, double* GB, hipStream_t s) {
@@ -105,9 +119,15 @@ __global__ void par2_xta_k(const double* X, const double* A, const double* Cfac,
   double* out = Ak + o * d.R;
   for (int e = threadIdx.x; e < Jk * d.R; e += blockDim.x) {
     const int j = e % Jk, r = e / Jk;
-    double acc = 0.0;
-    for (int i = 0; i < d.I; ++i) acc += Xk[i + (int64_t)d.I * j] * A[i + d.I * r];
-    out[e] = w * acc * Cfac[k + d.K * r];           // w * X_k' * A * diag(C(k,:))   (:193)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // independent partial sums (see par2_xkb_k)
+    int i = 0;
+    for (; i + 3 < d.I; i += 4) {
+      const double* x = Xk + i + (int64_t)d.I * j;
+      const double* a = A + i + d.I * r;
+      a0 += x[0] * a[0]; a1 += x[1] * a[1]; a2 += x[2] * a[2]; a3 += x[3] * a[3];
+    }
+    for (; i < d.I; ++i) a0 += Xk[i + (int64_t)d.I * j] * A[i + d.I * r];
+    out[e] = w * ((a0 + a1) + (a2 + a3)) * Cfac[k + d.K * r];           // w * X_k' * A * diag(C(k,:))   (:193)
   }
 }
 void par2_xta(const double* X, const double* A, const double* Cfac, double w, const P2Dims& d, double* Ak,
@@ -308,9 +328,16 @@ __device__ __forceinline__ void par2_deltab_part_dev(const P2BArgs& a, const P2D
     const int g = threadIdx.x / RR, e = threadIdx.x % RR;
     if (g < ng) {
       const int r = e % R, q = e / R;
-      double acc = 0.0;
-      for (int j = g; j < Jk; j += ng) acc += a.P[base + j + Jk * r] * (a.B[base + j + Jk * q] + a.mu[base + j + Jk * q]);
-      sh[g * RR + e] = acc;
+      double acc = 0.0, acc1 = 0.0;                   // two rows per step: six loads in flight instead of three
+      int j = g;
+      for (; j + ng < Jk; j += 2 * ng) {
+        const double p0 = a.P[base + j + Jk * r], p1 = a.P[base + j + ng + Jk * r];
+        const double b0 = a.B[base + j + Jk * q] + a.mu[base + j + Jk * q];
+        const double b1 = a.B[base + j + ng + Jk * q] + a.mu[base + j + ng + Jk * q];
+        acc += p0 * b0; acc1 += p1 * b1;
+      }
+      for (; j < Jk; j += ng) acc += a.P[base + j + Jk * r] * (a.B[base + j + Jk * q] + a.mu[base + j + Jk * q]);
+      sh[g * RR + e] = acc + acc1;
     }
     __syncthreads();
     if ((int)threadIdx.x < RR) {
@@ -894,7 +921,22 @@ __global__ __launch_bounds__(kP2ResThreads) void par2_residual_k(const double* X
   const double* Xk = X + (int64_t)I * o;
   const double* Bk = B + o * R;
   double acc = 0.0;
-  for (int e = threadIdx.x; e < I * Jk; e += blockDim.x) {
+  // four entries per step, their tensor loads issued together (one entry per step waited for its own load every time)
+  const int n = I * Jk, st = blockDim.x;
+  int e = threadIdx.x;
+  for (; e + 3 * st < n; e += 4 * st) {
+    const double x0 = Xk[e], x1 = Xk[e + st], x2 = Xk[e + 2 * st], x3 = Xk[e + 3 * st];
+    double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+    const int i0 = e % I, j0 = e / I, i1 = (e + st) % I, j1 = (e + st) / I;
+    const int i2 = (e + 2 * st) % I, j2 = (e + 2 * st) / I, i3 = (e + 3 * st) % I, j3 = (e + 3 * st) / I;
+    for (int r = 0; r < R; ++r) {
+      const double c = Cfac[k + d.K * r];
+      m0 += A[i0 + I * r] * c * Bk[j0 + Jk * r]; m1 += A[i1 + I * r] * c * Bk[j1 + Jk * r];
+      m2 += A[i2 + I * r] * c * Bk[j2 + Jk * r]; m3 += A[i3 + I * r] * c * Bk[j3 + Jk * r];
+    }
+    acc += (x0 - m0) * (x0 - m0); acc += (x1 - m1) * (x1 - m1); acc += (x2 - m2) * (x2 - m2); acc += (x3 - m3) * (x3 - m3);
+  }
+  for (; e < n; e += st) {
     const int i = e % I, j = e / I;
     double m = 0.0;
     for (int r = 0; r < R; ++r) m += A[i + I * r] * Cfac[k + d.K * r] * Bk[j + Jk * r];
