@@ -1069,13 +1069,23 @@ __global__ void reduce_outer_fin(const double* __restrict__ part, int SB, int64_
   if (idx >= A * R) return;
   const int64_t a = idx / R;
   const int r = (int)(idx - a * R);
+  // eight slices per step, their loads issued together: with two per step the up to 64 slices were 32 dependent L2
+  // round trips (11 us for 40,000 outputs); the sum keeps the even/odd pairing of the two-accumulator form
   double t0 = 0.0, t1 = 0.0;
   int s = 0;
-  for (; s + 1 < SB; s += 2) {
-    t0 += part[(int64_t)s * A * R + idx];
-    t1 += part[(int64_t)(s + 1) * A * R + idx];
+  const int64_t ar = A * R;
+  for (; s + 7 < SB; s += 8) {
+    const double v0 = part[(int64_t)s * ar + idx], v1 = part[(int64_t)(s + 1) * ar + idx];
+    const double v2 = part[(int64_t)(s + 2) * ar + idx], v3 = part[(int64_t)(s + 3) * ar + idx];
+    const double v4 = part[(int64_t)(s + 4) * ar + idx], v5 = part[(int64_t)(s + 5) * ar + idx];
+    const double v6 = part[(int64_t)(s + 6) * ar + idx], v7 = part[(int64_t)(s + 7) * ar + idx];
+    t0 += v0; t1 += v1; t0 += v2; t1 += v3; t0 += v4; t1 += v5; t0 += v6; t1 += v7;
   }
-  if (s < SB) t0 += part[(int64_t)s * A * R + idx];
+  for (; s + 1 < SB; s += 2) {
+    t0 += part[(int64_t)s * ar + idx];
+    t1 += part[(int64_t)(s + 1) * ar + idx];
+  }
+  if (s < SB) t0 += part[(int64_t)s * ar + idx];
   if (rowmajor) out[idx] = scale * (t0 + t1);         // T layout [a][r] for a further fold (N-way tensors)
   else out[a + ldOut * r] = scale * (t0 + t1);
 }

@@ -152,8 +152,15 @@ __global__ __launch_bounds__(256) void atb_fin_k(double* out, const double* ws, 
   const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + el;
   double t = 0.0;
-  if (e < KN)
-    for (int b = sl; b < nb; b += 8) t += ws[(int64_t)b * KN + e];
+  if (e < KN) {
+    int b = sl;
+    for (; b + 24 < nb; b += 32) {                 // four partials per step, loads issued together, added in order
+      const double v0 = ws[(int64_t)b * KN + e], v1 = ws[(int64_t)(b + 8) * KN + e];
+      const double v2 = ws[(int64_t)(b + 16) * KN + e], v3 = ws[(int64_t)(b + 24) * KN + e];
+      t += v0; t += v1; t += v2; t += v3;
+    }
+    for (; b < nb; b += 8) t += ws[(int64_t)b * KN + e];
+  }
   sh[sl][el] = t;
   __syncthreads();
   if (sl == 0 && e < KN) {
@@ -247,8 +254,15 @@ __global__ __launch_bounds__(256) void reduce_batch_k(ReduceBatch rb, double* ws
 __global__ void reduce_batch_fin_k(ReduceBatch rb, const double* ws, int nsplit) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= rb.n) return;
+  // the partial sums of a task are contiguous: eight loads per step in flight, added in index order
+  const double* w = ws + (int64_t)k * nsplit;
   double t = 0.0;
-  for (int q = 0; q < nsplit; ++q) t += ws[(int64_t)k * nsplit + q];
+  int q = 0;
+  for (; q + 7 < nsplit; q += 8) {
+    const double v0 = w[q], v1 = w[q + 1], v2 = w[q + 2], v3 = w[q + 3], v4 = w[q + 4], v5 = w[q + 5], v6 = w[q + 6], v7 = w[q + 7];
+    t += v0; t += v1; t += v2; t += v3; t += v4; t += v5; t += v6; t += v7;
+  }
+  for (; q < nsplit; ++q) t += w[q];
   rb.t[k].slot[0] = rb.t[k].scale * t;
 }
 void reduce_batch(const ReduceBatch& rb, double* ws, hipStream_t s) {
