@@ -113,15 +113,25 @@ __global__ void atb_part_k(const double* A, int64_t lda, const double* B, int64_
   for (int64_t r0 = i0; r0 < i1; r0 += kAtbRows) {
     const int nr = (int)((i1 - r0 < kAtbRows) ? (i1 - r0) : kAtbRows);
     __syncthreads();
-    for (int e = threadIdx.x; e < nr * K; e += blockDim.x) {
-      const int i = e % nr, k = e / nr;
-      ta[i * Kp + k] = A[r0 + i + lda * k];
-    }
-    for (int e = threadIdx.x; e < nr * N; e += blockDim.x) {
-      const int i = e % nr, n = e / nr;
-      tb[i * Np + n] = B[r0 + i + ldb * n];
-    }
+    // staging: four loads per thread issued before the first LDS store (one load per step made every step wait for its
+    // own round trip); a Gram matrix (A == B) stages its rows once
+    auto stage = [&](const double* M, int64_t ldm, int C, int Cp, double* dst) {
+      const int n = nr * C, st = blockDim.x;
+      int e = threadIdx.x;
+      for (; e + 3 * st < n; e += 4 * st) {
+        const int e1 = e + st, e2 = e + 2 * st, e3 = e + 3 * st;
+        const double v0 = M[r0 + e % nr + ldm * (e / nr)], v1 = M[r0 + e1 % nr + ldm * (e1 / nr)];
+        const double v2 = M[r0 + e2 % nr + ldm * (e2 / nr)], v3 = M[r0 + e3 % nr + ldm * (e3 / nr)];
+        dst[(e % nr) * Cp + e / nr] = v0; dst[(e1 % nr) * Cp + e1 / nr] = v1;
+        dst[(e2 % nr) * Cp + e2 / nr] = v2; dst[(e3 % nr) * Cp + e3 / nr] = v3;
+      }
+      for (; e < n; e += st) dst[(e % nr) * Cp + e / nr] = M[r0 + e % nr + ldm * (e / nr)];
+    };
+    const bool same = A == B && lda == ldb && K == N;
+    stage(A, lda, K, Kp, ta);
+    if (!same) stage(B, ldb, N, Np, tb);
     __syncthreads();
+    if (same) tb = ta;
     if (At)                                        // row-major copy of the staged rows (contiguous store)
       for (int e = threadIdx.x; e < nr * K; e += blockDim.x) {
         const int i = e / K, k = e - i * K;
@@ -407,7 +417,18 @@ __global__ __launch_bounds__(64) void sys_build_k(SysBuild sb) {
     const double* g0 = sb.ngram == 0 ? sb.Cpre : sb.grams[0];
 #pragma unroll
     for (int c = 0; c < RMAX; ++c) row[c] = g0[(mine ? t : 0) + R * (c < R ? c : 0)];
-    for (int k = 1; k < sb.ngram; ++k) {         // C = ones .* G_transp_G{j}...  (:98-103)
+    // C = ones .* G_transp_G{j}...  (:98-103).  The second matrix (3-way blocks have two) is loaded in the same round
+    // trip as the first: its loads are issued before the first product needs the first's values.
+    if (sb.ngram >= 2) {
+      const double* g1 = sb.grams[1];
+      double tmp[RMAX];
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) tmp[c] = g1[(mine ? t : 0) + R * (c < R ? c : 0)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < RMAX; ++c) row[c] *= tmp[c];
+    }
+    for (int k = 2; k < sb.ngram; ++k) {
       const double* g = sb.grams[k];
       double tmp[RMAX];
 #pragma unroll
