@@ -459,16 +459,22 @@ __global__ __launch_bounds__(64) void sys_build_k(SysBuild sb) {
   }
   // chol(B','lower') (:142), right-looking.  Lane t keeps L(t, 0..t); its entries right of the diagonal
   // are never read by another lane.
+  // One reciprocal square root per column instead of a square root and a division (each ~30 dependent fp64
+  // instructions on the kernel's single wave); the reciprocal diagonal is kept for the substitutions below.
   bool ok = true;
+  double invd[RMAX];
 #pragma unroll
   for (int j = 0; j < RMAX; ++j) {
+    invd[j] = 0.0;
     if (j < R && ok) {
       const double d = readlane_d(row[j], j);
       if (!(d > 0.0)) {
         ok = false;
       } else {
-        const double dj = sqrt(d);
-        const double lij = row[j] / dj;
+        const double inv = rsqrt(d);
+        const double dj = d * inv;
+        invd[j] = inv;
+        const double lij = row[j] * inv;
         row[j] = (t == j) ? dj : lij;
 #pragma unroll
         for (int k = j + 1; k < RMAX; ++k)
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(64) void sys_build_k(SysBuild sb) {
         double v = (i == t) ? 1.0 : 0.0;
 #pragma unroll
         for (int q = 0; q < i; ++q) v -= readlane_d(row[q], i) * xc[q];
-        xc[i] = v / readlane_d(row[i], i);
+        xc[i] = v * invd[i];
       }
     }
 #pragma unroll
