@@ -239,21 +239,45 @@ __global__ __launch_bounds__(256) void reduce_batch_k(ReduceBatch rb, double* ws
     const int64_t i0 = sp * per;
     int64_t i1 = i0 + per;
     if (i1 > tk.rows) i1 = tk.rows;
-#pragma unroll 4
-    for (int r = 0; r < tk.R; ++r) {
-      const double* x = tk.x + tk.rows * r;
-      for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-        const double v = x[i];
-        switch (tk.aux) {
-          case AOADMM_C_L1_REG: acc += fabs(v); break;
-          case AOADMM_C_L0_REG: acc += (v != 0.0) ? 1.0 : 0.0; break;
-          case AOADMM_C_RIDGE: acc += v * v; break;
-          case AOADMM_C_TV: if (i + 1 < tk.rows) acc += x[i + 1] - v; break;          // no abs(): quirk of :81
-          case AOADMM_C_GL_SMOOTH: if (i + 1 < tk.rows) { const double d = x[i + 1] - v; acc += d * d; } break;
-          default: break;
-        }
+    // (column, row) flattened and four entries per step with their loads issued together: column by column with one
+    // entry per step this was R * rows / 256 dependent round trips (the 30 us that made this kernel the longest of
+    // the objective evaluation)
+    const int64_t nloc = i1 > i0 ? i1 - i0 : 0, tot_e = nloc * tk.R;
+    const bool diff = tk.aux == AOADMM_C_TV || tk.aux == AOADMM_C_GL_SMOOTH;
+    auto term = [&](double v, double vn, bool has_next) {
+      switch (tk.aux) {
+        case AOADMM_C_L1_REG: return fabs(v);
+        case AOADMM_C_L0_REG: return (v != 0.0) ? 1.0 : 0.0;
+        case AOADMM_C_RIDGE: return v * v;
+        case AOADMM_C_TV: return has_next ? vn - v : 0.0;                              // no abs(): quirk of :81
+        case AOADMM_C_GL_SMOOTH: return has_next ? (vn - v) * (vn - v) : 0.0;
+        default: return 0.0;
       }
+    };
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int64_t e = threadIdx.x;
+    for (; e + 768 < tot_e; e += 1024) {
+      double v[4], vn[4];
+      bool hn[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t ee = e + 256 * q;
+        const int64_t r = ee / nloc, i = i0 + (ee - r * nloc);
+        const double* x = tk.x + tk.rows * r;
+        hn[q] = i + 1 < tk.rows;
+        v[q] = x[i];
+        vn[q] = (diff && hn[q]) ? x[i + 1] : 0.0;
+      }
+      a0 += term(v[0], vn[0], hn[0]); a1 += term(v[1], vn[1], hn[1]);
+      a2 += term(v[2], vn[2], hn[2]); a3 += term(v[3], vn[3], hn[3]);
     }
+    for (; e < tot_e; e += 256) {
+      const int64_t r = e / nloc, i = i0 + (e - r * nloc);
+      const double* x = tk.x + tk.rows * r;
+      const bool hn = i + 1 < tk.rows;
+      a0 += term(x[i], (diff && hn) ? x[i + 1] : 0.0, hn);
+    }
+    acc = (a0 + a1) + (a2 + a3);
   }
   const double tot = block256_sum(acc, sh4);
   if (threadIdx.x == 0) {
@@ -261,19 +285,14 @@ __global__ __launch_bounds__(256) void reduce_batch_k(ReduceBatch rb, double* ws
     else ws[(int64_t)blockIdx.y * nsplit + sp] = tot;
   }
 }
-__global__ void reduce_batch_fin_k(ReduceBatch rb, const double* ws, int nsplit) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= rb.n) return;
-  // the partial sums of a task are contiguous: eight loads per step in flight, added in index order
-  const double* w = ws + (int64_t)k * nsplit;
+// one wave per task (the task record is then addressed by a uniform index: a per-thread index into the by-value
+// argument made every thread copy the whole batch to scratch first); lanes hold the partial sums, DPP tree
+__global__ __launch_bounds__(64) void reduce_batch_fin_k(ReduceBatch rb, const double* ws, int nsplit) {
+  const ReduceTask& tk = rb.t[blockIdx.x];
   double t = 0.0;
-  int q = 0;
-  for (; q + 7 < nsplit; q += 8) {
-    const double v0 = w[q], v1 = w[q + 1], v2 = w[q + 2], v3 = w[q + 3], v4 = w[q + 4], v5 = w[q + 5], v6 = w[q + 6], v7 = w[q + 7];
-    t += v0; t += v1; t += v2; t += v3; t += v4; t += v5; t += v6; t += v7;
-  }
-  for (; q < nsplit; ++q) t += w[q];
-  rb.t[k].slot[0] = rb.t[k].scale * t;
+  for (int q = threadIdx.x; q < nsplit; q += 64) t += ws[(int64_t)blockIdx.x * nsplit + q];
+  t = wave_sum(t);
+  if (threadIdx.x == 0) tk.slot[0] = tk.scale * t;
 }
 void reduce_batch(const ReduceBatch& rb, double* ws, hipStream_t s) {
   if (rb.n <= 0) return;
@@ -285,7 +304,7 @@ void reduce_batch(const ReduceBatch& rb, double* ws, hipStream_t s) {
   reduce_batch_k<<<dim3((unsigned)nsplit, (unsigned)rb.n), 256, 0, s>>>(rb, ws);
   AO_KERNEL_CHECK();
   if (nsplit > 1) {
-    reduce_batch_fin_k<<<1, 64, 0, s>>>(rb, ws, nsplit);
+    reduce_batch_fin_k<<<(unsigned)rb.n, 64, 0, s>>>(rb, ws, nsplit);
     AO_KERNEL_CHECK();
   }
 }
