@@ -299,7 +299,7 @@ void reduce_batch(const ReduceBatch& rb, double* ws, hipStream_t s) {
   AO_REQUIRE(rb.n <= kReduceBatchMax, "reduce_batch: too many tasks");
   int64_t big = 0;
   for (int k = 0; k < rb.n; ++k) big = std::max<int64_t>(big, rb.t[k].kind >= RT_REG ? rb.t[k].rows * rb.t[k].R : rb.t[k].n);
-  int nsplit = (int)std::min<int64_t>(kReduceBatchSplit, cdiv(big, 8192));
+  int nsplit = (int)std::min<int64_t>(kReduceBatchSplit, cdiv(big, 2048));   // two steps of four loads per thread: the kernel is latency, not bandwidth
   if (nsplit < 1) nsplit = 1;
   reduce_batch_k<<<dim3((unsigned)nsplit, (unsigned)rb.n), 256, 0, s>>>(rb, ws);
   AO_KERNEL_CHECK();
