@@ -252,7 +252,8 @@ class Engine {
   void coupled_admm(int c, const aoadmm_options& opt);
   void eval_objective_enqueue(bool first);
   bool has_missing() const;
-  void em_pass_enqueue(int p, int update, bool fuse_next_pass = false);         // statistics of tensor p into its EM slots (+ imputation)
+  void em_pass_enqueue(int p, int update, bool fuse_next_pass = false);
+  void prepare_next_first_mode(const aoadmm_options& opt);         // statistics of tensor p into its EM slots (+ imputation)
   double* em_slot(int p) const;
   void ensure_mode_work(ModeInfo& mi);
   // PARAFAC2 (solver_par2.hip)
@@ -284,6 +285,7 @@ class Engine {
   DevBuf atbws_;
   DevBuf staging_;
   KernelStats kstats_[3];   // [0] streaming contraction, [1] leading-mode contraction, [2] reductions over T
+  int prepared_mode_ = -1;  // mode whose MTTKRP + system build were enqueued ahead (prepare_next_first_mode)
   bool profile_ = true;
   bool profile_reductions_ = false;   // switched on by the first kernel_stats(2, ...) call: two more events per reduction
   ncclComm_t comm_ = nullptr;

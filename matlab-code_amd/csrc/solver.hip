@@ -923,7 +923,8 @@ void Engine::timed_contract(const void* X, int prec, const ContractPlan& pl, con
                             void* frag, void* T) {
   KernelStats& ks = kstats_[pl.lead ? 1 : 0];
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (profile_ && ks.pending.size() < 100000) {
+  static const bool no_events = getenv("AOADMM_NO_PASS_EVENTS") != nullptr;   // development switch (tools/gap_analysis.py)
+  if (profile_ && !no_events && ks.pending.size() < 100000) {
     AO_HIP(hipEventCreate(&e0));
     AO_HIP(hipEventCreate(&e1));
   }
@@ -1385,9 +1386,25 @@ void Engine::prepare_mode_system(int m, int nrho, const aoadmm_options& opt) {
   }
 }
 
+// see the end of the outer loop in solve(): the first uncoupled CP mode of the next iteration, prepared ahead
+void Engine::prepare_next_first_mode(const aoadmm_options& opt) {
+  static const bool off = getenv("AOADMM_NO_PREPARE_AHEAD") != nullptr;      // development switch
+  if (off) return;
+  for (int p = 0; p < n_tensors_; ++p)
+    for (int m = 0; m < n_modes_; ++m) {
+      const ModeInfo& mi = modes_[m];
+      if (mi.coupling != -1 || mi.tensor != p) continue;
+      if (tensors_[p].par2) return;                 // the first mode updated is a PARAFAC2 mode: nothing ahead
+      prepare_mode_system(m, mi.constrained ? 1 : 0, opt);
+      prepared_mode_ = m;
+      return;
+    }
+}
+
 void Engine::update_uncoupled_cp_mode(int m, const aoadmm_options& opt) {
   ModeInfo& mi = modes_[m];
-  prepare_mode_system(m, mi.constrained ? 1 : 0, opt);
+  if (prepared_mode_ == m) prepared_mode_ = -1;     // MTTKRP and system were enqueued at the end of the last iteration
+  else prepare_mode_system(m, mi.constrained ? 1 : 0, opt);
   AdmmCtl* ctl = ctl_of_mode(m);
   LoopEnd le;
   GramFold gf;
@@ -2803,6 +2820,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   AO_REQUIRE(out != nullptr, "null result");
   AO_REQUIRE(opt.MaxOuterIters >= 0 && opt.MaxInnerIters >= 1, "bad iteration limits");
   AO_HIP(hipSetDevice(device_));
+  prepared_mode_ = -1;                                // nothing prepared ahead by an earlier solve is valid for this state
   allow_xp_ = opt.no_permuted_copy == 0;
   if (!allow_xp_)
     for (int p = 0; p < n_tensors_; ++p)
@@ -3032,6 +3050,11 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
       } else {
         eval_objective_enqueue(false);                                         // :447
         enqueue_readback();
+        // No pass to hide behind: the host now waits ~45 us for the read-back before it can enqueue anything, and the
+        // GPU would sit idle.  The MTTKRP (reductions over the cached T) and the system build of the next iteration's
+        // first mode depend on no stopping decision and write only that mode's scratch (A, C, rho, B, L, inv, ctl --
+        // behind the read-back of this iteration's loop counters in stream order): enqueue them now.
+        if (!has_miss) prepare_next_first_mode(opt);
       }
     } else {
       eval_objective_enqueue(false);                                           // :447
