@@ -284,6 +284,8 @@ class Engine {
   bool allow_xp_ = true;  // options.hip.no_permuted_copy
   DevBuf atbws_;
   DevBuf staging_;
+  std::vector<hipEvent_t> event_pool_;   // timing events are recycled: creating two per tensor pass cost host time in the loop
+  hipEvent_t take_event();
   KernelStats kstats_[3];   // [0] streaming contraction, [1] leading-mode contraction, [2] reductions over T
   int prepared_mode_ = -1;  // mode whose MTTKRP + system build were enqueued ahead (prepare_next_first_mode)
   bool profile_ = true;

@@ -52,6 +52,7 @@ Engine::~Engine() {
   (void)hipSetDevice(device_);
   for (auto& ks : kstats_)
     for (auto& pr : ks.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (hipEvent_t e : event_pool_) (void)hipEventDestroy(e);
   if (comm_) (void)ncclCommDestroy(comm_);
   if (side_ev_) (void)hipEventDestroy(side_ev_);
   if (side_) (void)hipStreamDestroy(side_);
@@ -919,14 +920,27 @@ void Engine::state_get(int field, int index, int slab, double* host, int64_t row
 // ---------------------------------------------------------------------------
 // MTTKRP engine
 // ---------------------------------------------------------------------------
+hipEvent_t Engine::take_event() {
+  if (event_pool_.empty()) {
+    for (int i = 0; i < 64; ++i) {
+      hipEvent_t e = nullptr;
+      AO_HIP(hipEventCreate(&e));
+      event_pool_.push_back(e);
+    }
+  }
+  hipEvent_t e = event_pool_.back();
+  event_pool_.pop_back();
+  return e;
+}
+
 void Engine::timed_contract(const void* X, int prec, const ContractPlan& pl, const double* F, int64_t ldF,
                             void* frag, void* T) {
   KernelStats& ks = kstats_[pl.lead ? 1 : 0];
   hipEvent_t e0 = nullptr, e1 = nullptr;
   static const bool no_events = getenv("AOADMM_NO_PASS_EVENTS") != nullptr;   // development switch (tools/gap_analysis.py)
   if (profile_ && !no_events && ks.pending.size() < 100000) {
-    AO_HIP(hipEventCreate(&e0));
-    AO_HIP(hipEventCreate(&e1));
+    e0 = take_event();
+    e1 = take_event();
   }
   launch_contract(X, prec, pl, F, ldF, frag, T, stream_, e0, e1);
   if (e0) ks.pending.emplace_back(e0, e1);
@@ -945,8 +959,8 @@ void Engine::kernel_stats(int which, int reset, double* ms, int64_t* launches, d
     float t = 0.f;
     AO_HIP(hipEventElapsedTime(&t, pr.first, pr.second));
     ks.ms += t;
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
+    event_pool_.push_back(pr.first);
+    event_pool_.push_back(pr.second);
   }
   ks.pending.clear();
   if (ms) *ms = ks.ms;
@@ -1218,8 +1232,8 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
     KernelStats& rs = kstats_[2];
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile_ && profile_reductions_ && rs.pending.size() < 100000) {
-      AO_HIP(hipEventCreate(&e0));
-      AO_HIP(hipEventCreate(&e1));
+      e0 = take_event();
+      e1 = take_event();
       AO_HIP(hipEventRecord(e0, stream_));
     }
     if (pos == ia) {
