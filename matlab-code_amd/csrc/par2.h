@@ -45,6 +45,11 @@ struct P2BArgs {
   const double *Z, *muZ;               // constraint variables (nullable)
   double* norms;                       // [K][8]
   int use_constr;
+  // One-sided Jacobi of the polar factor (:532-534), warm start: the rotation the previous inner iteration ended with
+  // ([K][R*R], column-major per slab) is applied first, so the sweeps start from almost orthogonal columns.  A speed
+  // hint only (any orthogonal start gives the same polar factor).  null: cold start from the identity.
+  double* Jrot = nullptr;
+  int jrot_valid = 0;                  // 0: Jrot holds nothing yet (first inner iteration): cold start, then store
 };
 // one inner iteration of ADMM_B_Parafac2 up to (not including) the constraint update   (:525-547, :582-585)
 // psum (R*R+1 doubles) != nullptr: slabs are sharded, DeltaB's sums go through `allreduce`

@@ -258,7 +258,8 @@ __device__ __forceinline__ void par2_b_primal_dev(const P2BArgs& a, const P2Dims
 // itself and nothing is exchanged through memory.  W_k is staged in LDS when it fits (in_lds), else rotated in place.
 static_assert(kP2Threads == 64, "par2_polar_dev reduces over exactly one wavefront");
 __device__ inline double wave_sum64(double v) { return wave_sum(v); }   // DPP tree (device_utils.h), the same bits in every lane
-__device__ __forceinline__ void par2_polar_dev(double* W, double* P, const P2Dims& d, int k, int in_lds, double* Jr) {
+__device__ __forceinline__ void par2_polar_dev(double* W, double* P, const P2Dims& d, int k, int in_lds, double* Jr,
+                                              double* Jwarm = nullptr, int warm_valid = 0) {
   const int R = d.R, lane = threadIdx.x;  // Jr: R*R, then W_k (n*R) when in_lds
   const int64_t o = d.off[k];
   const int n = (int)(d.off[k + 1] - o);
@@ -269,8 +270,20 @@ __device__ __forceinline__ void par2_polar_dev(double* W, double* P, const P2Dim
     for (int e = lane; e < n * R; e += 64) Wl[e] = Wk[e];
     Wk = Wl;
   }
-  for (int e = lane; e < R * R; e += 64) Jr[e] = (e % R == e / R) ? 1.0 : 0.0;
+  const bool warm = Jwarm != nullptr && warm_valid && in_lds;   // needs the untouched copy in global memory as source
+  for (int e = lane; e < R * R; e += 64) Jr[e] = warm ? Jwarm[(int64_t)k * R * R + e] : ((e % R == e / R) ? 1.0 : 0.0);
   __syncthreads();
+  if (warm) {
+    // W <- W * J_prev, row by row (each lane owns its rows): the columns are almost orthogonal before the first sweep
+    const double* Wg = W + o * R;                      // the slab as the primal step left it
+    for (int e = lane; e < n * R; e += 64) {
+      const int i = e % n, p = e / n;
+      double acc = 0.0;
+      for (int q = 0; q < R; ++q) acc += Wg[i + n * q] * Jr[q + R * p];
+      Wk[e] = acc;
+    }
+    __syncthreads();
+  }
   for (int sweep = 0; sweep < 60; ++sweep) {
     bool rotated = false;
     for (int p = 0; p < R - 1; ++p)
@@ -308,6 +321,8 @@ __device__ __forceinline__ void par2_polar_dev(double* W, double* P, const P2Dim
     for (int i = lane; i < n; i += 64) wp[i] = sg > 0 ? wp[i] / sg : 0.0;
   }
   __syncthreads();
+  if (Jwarm != nullptr)
+    for (int e = lane; e < R * R; e += 64) Jwarm[(int64_t)k * R * R + e] = Jr[e];
   for (int e = lane; e < n * R; e += 64) {
     const int i = e % n, r = e / n;
     double acc = 0.0;
@@ -469,7 +484,7 @@ __global__ __launch_bounds__(kP2Threads) void par2_b_slab_fold_k(P2BArgs a, P2Di
   const int k = d.k0 + blockIdx.x;
   par2_b_primal_dev<RMAX>(a, d, k, sh);
   __syncthreads();
-  par2_polar_dev(a.W, a.P, d, k, in_lds, sh);
+  par2_polar_dev(a.W, a.P, d, k, in_lds, sh, a.Jrot, a.jrot_valid);
   __syncthreads();
   par2_deltab_part_dev(a, d, k, sh);
 }
@@ -569,6 +584,7 @@ void par2_b_loop_folded(const P2BArgs& a0, const P2Dims& d, AdmmCtl* ctl, int ma
     P2BArgs a = a0;
     a.DeltaB = (it & 1) ? a0.DeltaBold : a0.DeltaB;
     a.DeltaBold = (it & 1) ? a0.DeltaB : a0.DeltaBold;
+    a.jrot_valid = it >= 1 ? 1 : 0;                  // the first inner iteration of every loop starts cold
     f.it = it;
     if (d.R <= 4) par2_b_slab_fold_k<4><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds, f);
     else par2_b_slab_fold_k<8><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds, f);

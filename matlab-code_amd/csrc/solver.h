@@ -111,6 +111,7 @@ struct Par2Block {
   bool has_DeltaB = false;
   std::vector<char> have_P, have_mu;
   DevBuf W, T1, GB, Ak, Lk, rhok, part, norms, res, q, regv, Csys, ac, Lc, rhoc, rhomax;
+  DevBuf Jrot;                                     // [K][R*R]: last Jacobi rotation per slab (warm start inside a B_k loop)
   // slab sharding over the ranks of a communicator (aoadmm_options.par2_slab_sharding): this rank runs the per-slab
   // kernels on [k0, k1) only; every sum over k is all-reduced, slab-valued state is gathered when the solve ends
   bool slab_sharded = false;

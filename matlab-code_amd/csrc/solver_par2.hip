@@ -178,6 +178,8 @@ void Engine::par2_update_B(int m, const aoadmm_options& opt, int iter) {
   a.Z = constr ? mi.Z.d() : nullptr; a.muZ = constr ? mi.mu.d() : nullptr;
   a.norms = b.norms.d();
   a.use_constr = constr ? 1 : 0;
+  b.Jrot.ensure((size_t)b.K * b.R * b.R * sizeof(double));
+  a.Jrot = b.Jrot.d();
   const P2AllReduce ar = [this](double* buf, int64_t n) { allreduce(buf, n); };
   double* psum = b.slab_sharded ? b.psum.d() : nullptr;
   double* part4 = b.slab_sharded ? b.psum.d() + (int64_t)b.R * b.R + 8 : nullptr;
