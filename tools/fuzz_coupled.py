@@ -25,53 +25,62 @@ def flat(x, out):
     else:
         out.append(np.asarray(x, dtype=float))
 
+def one_case(eng, case):
+    """Runs one randomly drawn model on both MTTKRP paths; returns the list of mismatch reports (empty = parity)."""
+    fails = []
+    rng = np.random.default_rng(20_000 + case)
+    fam = case % 3
+    rows = int(rng.integers(5, 320))
+    if fam == 0:
+        Z, io = script3_model(rng, rows=rows)
+        free = [1, 2, 4]
+    elif fam == 1:
+        Z, io = cp_cp_exact_model(rng, rows=rows)
+        free = [1, 2, 4, 5]
+    else:
+        Z, io = script1_model(rng, dims=(int(rng.integers(5, 60)), int(rng.integers(5, 40)), int(rng.integers(5, 40))),
+                              K=int(rng.integers(2, 40)), Jk=int(rng.integers(4, 50)), noise=0.05)
+        free = [1, 2]
+    Z = dict(Z); Z['constraints'] = list(Z['constraints']); Z['constrained_modes'] = list(Z['constrained_modes'])
+    for m in free:
+        c = ROWCELLS[int(rng.integers(0, len(ROWCELLS)))]
+        Z['constraints'][m] = c
+        Z['constrained_modes'][m] = 0 if c is None else 1
+    inner = int(rng.integers(1, 8))
+    opt = options(MaxOuterIters=int(rng.integers(2, 6)), MaxInnerIters=inner)
+    for path in ('one-launch', 'tensor-pass'):
+        if path == 'tensor-pass':
+            os.environ['AOADMM_NO_SMALL_MTTKRP'] = '1'
+        else:
+            os.environ.pop('AOADMM_NO_SMALL_MTTKRP', None)
+        try:
+            G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(case))
+            _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
+            _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=eng)
+            a, b = [], []
+            for key in ('fac', 'constraint_fac', 'coupling_fac'):
+                flat(Fo[key], a); flat(Fg[key], b)
+            errs = [rel_fro(y, x) for x, y in zip(a, b)]
+            ok = len(a) == len(b) and all(e < 1e-7 for e in errs) and np.array_equal(og['innerIters'], oo['innerIters'])
+            errs = ['%.1e' % max(errs)]
+        except Exception as e:
+            ok = False
+            errs = [repr(e)[:300]]
+        if not ok:
+            fails.append(('CASE', case, path, 'family', fam, 'rows', rows, Z['constraints'], 'inner', inner, errs))
+    os.environ.pop('AOADMM_NO_SMALL_MTTKRP', None)
+    return fails
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     eng = pkg.Engine(0)
     bad = 0
     for case in range(s0, s0 + n):
-        rng = np.random.default_rng(20_000 + case)
-        fam = case % 3
-        rows = int(rng.integers(5, 320))
-        if fam == 0:
-            Z, io = script3_model(rng, rows=rows)
-            free = [1, 2, 4]
-        elif fam == 1:
-            Z, io = cp_cp_exact_model(rng, rows=rows)
-            free = [1, 2, 4, 5]
-        else:
-            Z, io = script1_model(rng, dims=(int(rng.integers(5, 60)), int(rng.integers(5, 40)), int(rng.integers(5, 40))),
-                                  K=int(rng.integers(2, 40)), Jk=int(rng.integers(4, 50)), noise=0.05)
-            free = [1, 2]
-        Z = dict(Z); Z['constraints'] = list(Z['constraints']); Z['constrained_modes'] = list(Z['constrained_modes'])
-        for m in free:
-            c = ROWCELLS[int(rng.integers(0, len(ROWCELLS)))]
-            Z['constraints'][m] = c
-            Z['constrained_modes'][m] = 0 if c is None else 1
-        inner = int(rng.integers(1, 8))
-        opt = options(MaxOuterIters=int(rng.integers(2, 6)), MaxInnerIters=inner)
-        for path in ('one-launch', 'tensor-pass'):
-            if path == 'tensor-pass':
-                os.environ['AOADMM_NO_SMALL_MTTKRP'] = '1'
-            else:
-                os.environ.pop('AOADMM_NO_SMALL_MTTKRP', None)
-            try:
-                G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(case))
-                _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
-                _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=eng)
-                a, b = [], []
-                for key in ('fac', 'constraint_fac', 'coupling_fac'):
-                    flat(Fo[key], a); flat(Fg[key], b)
-                errs = [rel_fro(y, x) for x, y in zip(a, b)]
-                ok = len(a) == len(b) and all(e < 1e-7 for e in errs) and np.array_equal(og['innerIters'], oo['innerIters'])
-                errs = ['%.1e' % max(errs)]
-            except Exception as e:
-                ok = False
-                errs = [repr(e)[:300]]
-            if not ok:
-                bad += 1
-                print('CASE', case, path, 'family', fam, 'rows', rows, Z['constraints'], 'inner', inner, errs, flush=True)
+        for f in one_case(eng, case):
+            bad += 1
+            print(*f, flush=True)
         if case % 10 == 9:
             print('... %d cases, %d bad' % (case - s0 + 1, bad), flush=True)
     os.environ.pop('AOADMM_NO_SMALL_MTTKRP', None)

@@ -16,50 +16,59 @@ CELLS = [None, ('non-negativity',), ('box', 0.0, 0.7), ('simplex column-wise', 1
          ('l1 regularization', 0.01), ('l0 regularization', 0.001), ('l2 regularization', 0.01), ('ridge', 0.05),
          ('GL smoothness', 0.1), ('TV regularization', 0.005)]
 
+def one_case(eng, case):
+    """Runs one randomly drawn model on both MTTKRP paths; returns the list of mismatch reports (empty = parity)."""
+    fails = []
+    rng = np.random.default_rng(10_000 + case)
+    nd = 3 if rng.random() < 0.8 else 2
+    dims = tuple(int(rng.integers(6, 90)) for _ in range(nd))
+    R = int(rng.integers(1, 7))
+    cons = []
+    for d in dims:
+        c = CELLS[int(rng.integers(0, len(CELLS)))]
+        if c is not None and c[0] == 'orthonormal' and d < R:
+            c = ('non-negativity',)
+        cons.append(c)
+    prec = 'f32' if rng.random() < 0.25 else 'f64'
+    Z, io, _ = cp_model(dims, R, rng, cons)
+    if rng.random() < 0.2:
+        mask = rng.random(dims) > 0.15
+        X = np.array(Z['object'][0], dtype=float)
+        X[~mask] = 0.0
+        Z['object'] = [X]
+        Z['miss'] = [mask]
+    inner = int(rng.integers(1, 8))
+    opt = options(MaxOuterIters=int(rng.integers(2, 7)), MaxInnerIters=inner)
+    for path in ('one-launch', 'tensor-pass'):
+        if path == 'tensor-pass':
+            os.environ['AOADMM_NO_SMALL_MTTKRP'] = '1'
+        else:
+            os.environ.pop('AOADMM_NO_SMALL_MTTKRP', None)
+        try:
+            G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(case))
+            _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
+            _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=eng, precision=prec)
+            tol = 2e-4 if prec == 'f32' else 1e-7
+            errs = [rel_fro(b, a) for a, b in zip(Fo['fac'], Fg['fac'])]
+            ok = all(e < tol for e in errs)
+        except Exception as e:
+            ok = False
+            errs = [repr(e)[:200]]
+        if not ok:
+            fails.append(('CASE', case, path, dims, 'R', R, cons, prec, 'miss' if 'miss' in Z else '', 'inner', inner, errs))
+    os.environ.pop('AOADMM_NO_SMALL_MTTKRP', None)
+    return fails
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     eng = pkg.Engine(0)
     bad = 0
     for case in range(s0, s0 + n):
-        rng = np.random.default_rng(10_000 + case)
-        nd = 3 if rng.random() < 0.8 else 2
-        dims = tuple(int(rng.integers(6, 90)) for _ in range(nd))
-        R = int(rng.integers(1, 7))
-        cons = []
-        for d in dims:
-            c = CELLS[int(rng.integers(0, len(CELLS)))]
-            if c is not None and c[0] == 'orthonormal' and d < R:
-                c = ('non-negativity',)
-            cons.append(c)
-        prec = 'f32' if rng.random() < 0.25 else 'f64'
-        Z, io, _ = cp_model(dims, R, rng, cons)
-        if rng.random() < 0.2:
-            mask = rng.random(dims) > 0.15
-            X = np.array(Z['object'][0], dtype=float)
-            X[~mask] = 0.0
-            Z['object'] = [X]
-            Z['miss'] = [mask]
-        inner = int(rng.integers(1, 8))
-        opt = options(MaxOuterIters=int(rng.integers(2, 7)), MaxInnerIters=inner)
-        for path in ('one-launch', 'tensor-pass'):
-            if path == 'tensor-pass':
-                os.environ['AOADMM_NO_SMALL_MTTKRP'] = '1'
-            else:
-                os.environ.pop('AOADMM_NO_SMALL_MTTKRP', None)
-            try:
-                G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(case))
-                _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
-                _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=eng, precision=prec)
-                tol = 2e-4 if prec == 'f32' else 1e-7
-                errs = [rel_fro(b, a) for a, b in zip(Fo['fac'], Fg['fac'])]
-                ok = all(e < tol for e in errs)
-            except Exception as e:
-                ok = False
-                errs = [repr(e)[:200]]
-            if not ok:
-                bad += 1
-                print('CASE', case, path, dims, 'R', R, cons, prec, 'miss' if 'miss' in Z else '', 'inner', inner, errs, flush=True)
+        for f in one_case(eng, case):
+            bad += 1
+            print(*f, flush=True)
         if case % 20 == 19:
             print('... %d cases, %d bad' % (case - s0 + 1, bad), flush=True)
     os.environ.pop('AOADMM_NO_SMALL_MTTKRP', None)
