@@ -85,8 +85,8 @@ void admm_constrained_loop(const AdmmMode& m, double* part, double* V, double* Z
 // row-major copy of the new factor.
 struct WgLoopU {
   const double* A;          // right-hand side, rows x R column-major (ld = rows)
-  const double* Binv;       // inv(L*L'), R x R (shared system), or null
-  const double* L;          // Cholesky factor: R x R (shared, used when Binv is null) or [rows][R*R] with per_row
+  const double* Binv;       // inv(L*L'), R x R (shared system; unused with per_row)
+  const double* L;          // with per_row: the rows' Cholesky factors, [rows][R*R]
   const double* rho;        // device scalar, or one value per row with per_row
   const double* rho_prox;   // device scalar the prox sees (max(rho) for a PARAFAC2 C mode, :1423-1424)
   double *fac, *Z, *mu;     // rows x R each

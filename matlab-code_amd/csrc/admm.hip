@@ -1319,17 +1319,16 @@ __device__ __forceinline__ void wg_sum(double (&v)[NV], double* red /* [NW][NV] 
   __syncthreads();
 }
 
-// SOLVE: 0 = inv(L*L') shared, 1 = L shared, 2 = one factor per row.  For 0 and 1 the matrix sits in LDS as an
-// RMAX x RMAX block padded with zeros (reciprocal diagonal 0 beyond the rank) and the row operands are padded with
-// zeros, so the solve is straight-line code without rank tests; a padded column stays exactly zero.
+// SOLVE: 0 = inv(L*L') shared by all rows, 2 = one Cholesky factor per row.  For 0 the matrix sits in LDS as an
+// RMAX x RMAX block padded with zeros and the row operands are padded with zeros, so the solve is straight-line code
+// without rank tests; a padded column stays exactly zero.
 template <int RMAX, int NT, int SOLVE>
 __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
   constexpr int NW = NT / 64;
-  extern __shared__ double lds[];                    // M[RMAX*RMAX] | invd[RMAX] | red[NW][max(RMAX,4)] | fsh[rows][RP] (Gram)
+  extern __shared__ double lds[];                    // M[RMAX*RMAX] | red[NW][max(RMAX,4)] | fsh[rows][RP] (Gram)
   constexpr int NRED = RMAX > 4 ? RMAX : 4;
   double* Msh = lds;
-  double* invd = lds + RMAX * RMAX;
-  double* red = invd + RMAX;
+  double* red = lds + RMAX * RMAX;
   double* fsh = red + NW * NRED;
   AdmmCtl* ctl = a.ctl;
   if (!a.reset && ctl->active == 0) return;          // a failed factorisation (sys_build) leaves the state untouched
@@ -1347,12 +1346,10 @@ __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
     x[c] = 0.0;
   }
   if (SOLVE != 2) {
-    const double* Msrc = SOLVE == 0 ? a.Binv : a.L;
     for (int e = t; e < RMAX * RMAX; e += NT) {
       const int r = e % RMAX, c = e / RMAX;
-      Msh[e] = (r < R && c < R) ? Msrc[r + R * c] : 0.0;
+      Msh[e] = (r < R && c < R) ? a.Binv[r + R * c] : 0.0;
     }
-    if (t < RMAX) invd[t] = (SOLVE == 1 && t < R) ? 1.0 / Msrc[t + R * t] : 0.0;
   }
   const double rho = SOLVE == 2 ? a.rho[i] : a.rho[0];
   const double rho_prox = a.rho_prox[0];             // max(rho) of a PARAFAC2 C mode (:1423-1424); rho otherwise
@@ -1393,7 +1390,7 @@ __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
           x[r] = v / Lk[r + R * r];
         }
       }
-    } else if (SOLVE == 0) {
+    } else {
       double y[RMAX];
 #pragma unroll
       for (int c = 0; c < RMAX; ++c) {
@@ -1404,21 +1401,6 @@ __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
       }
 #pragma unroll
       for (int c = 0; c < RMAX; ++c) x[c] = y[c];
-    } else {
-#pragma unroll
-      for (int r = 0; r < RMAX; ++r) {               // x * inv(L*L'): forward, then backward substitution
-        double v = x[r];
-#pragma unroll
-        for (int q = 0; q < r; ++q) v -= Msh[r + RMAX * q] * x[q];
-        x[r] = v * invd[r];
-      }
-#pragma unroll
-      for (int r = RMAX - 1; r >= 0; --r) {
-        double v = x[r];
-#pragma unroll
-        for (int q = r + 1; q < RMAX; ++q) v -= Msh[q + RMAX * r] * x[q];
-        x[r] = v * invd[r];
-      }
     }
     // update_constraint (:1420-1429): Z = prox(fac + mu), mu += fac - Z
     double zn[RMAX];
@@ -1534,7 +1516,7 @@ __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
 
 size_t admm_loop_wg_lds(int rmax, int nt, int64_t rows, bool gram) {
   const int nred = rmax > 4 ? rmax : 4;
-  return ((size_t)rmax * rmax + rmax + (size_t)(nt / 64) * nred + (gram ? (size_t)rows * (rmax | 1) : 0)) * sizeof(double);
+  return ((size_t)rmax * rmax + (size_t)(nt / 64) * nred + (gram ? (size_t)rows * (rmax | 1) : 0)) * sizeof(double);
 }
 
 bool admm_loop_wg_ok(int64_t rows, int R, int ptype, int max_inner) {
@@ -1547,12 +1529,11 @@ bool admm_loop_wg_ok(int64_t rows, int R, int ptype, int max_inner) {
 void admm_loop_wg(const WgLoopU& a, hipStream_t s) {
   AO_REQUIRE(admm_loop_wg_ok(a.rows, a.R, a.ptype, a.max_inner), "admm_loop_wg: mode too large for the one-workgroup loop");
   const bool gram = a.gram != nullptr;
-  const int solve = a.per_row ? 2 : (a.Binv ? 0 : 1);
+  AO_REQUIRE(a.per_row ? a.L != nullptr : a.Binv != nullptr, "admm_loop_wg: the shared system comes as inv(L*L'), per-row systems as factors");
   auto go = [&](auto rm) {
     constexpr int RM = decltype(rm)::value;
     const size_t lds = admm_loop_wg_lds(RM, kWgLoopRows, a.rows, gram);
-    if (solve == 0) admm_loop_wg_k<RM, kWgLoopRows, 0><<<1, kWgLoopRows, lds, s>>>(a);
-    else if (solve == 1) admm_loop_wg_k<RM, kWgLoopRows, 1><<<1, kWgLoopRows, lds, s>>>(a);
+    if (!a.per_row) admm_loop_wg_k<RM, kWgLoopRows, 0><<<1, kWgLoopRows, lds, s>>>(a);
     else admm_loop_wg_k<RM, kWgLoopRows, 2><<<1, kWgLoopRows, lds, s>>>(a);
   };
   if (a.R <= 4) go(std::integral_constant<int, 4>());
