@@ -282,7 +282,8 @@ def test_em_missing_fp32_tensor(pkg, eng):
 
 
 @pytest.mark.parametrize('dims,R,prec', [((70, 200, 30), 5, 'f64'), ((70, 200, 30), 5, 'f32'),
-                                         ((9, 400, 500), 20, 'f32'), ((130, 300), 7, 'f64')])
+                                         ((9, 400, 500), 20, 'f32'), ((130, 300), 7, 'f64'),
+                                         ((24, 70, 9), 33, 'f64'), ((24, 70, 9), 33, 'f32')])    # R > 32: one row per thread
 def test_em_missing_column_pieces(pkg, eng, dims, R, prec):
     """The EM pass cuts the second mode into pieces of whole 64-column tiles (em.hip: em_chunking): several pieces per
     slab with a short last one, several tiles per piece, a ragged first mode, ranks in different register classes."""
