@@ -769,6 +769,9 @@ void Engine::em_pass_enqueue(int p, int update, bool fuse_next_pass) {
       const int dist = next_update_distance(pos0, cand, seq.data(), (int)seq.size());
       if (dist > best) { best = dist; fused_c = cand; }
     }
+    // test hook (read per call): contract the second mode whenever that is allowed, so that the strip's walk along
+    // mode 2 with the fused contraction is exercised by models whose update order would never pick it
+    if (getenv("AOADMM_EM_FUSE_SECOND_MODE") != nullptr && pos0 != 1) fused_c = 1;
     const int64_t J = b.dims[1], K = b.dims[2];
     a.walk = fused_c == 1 ? 1 : 2;
     fpl = fused_c == 2 ? make_plan(1, 0, a.Ipad * J, a.Ipad * J, K, a.R, b.X.prec)

@@ -246,6 +246,24 @@ def test_em_missing_cp(pkg, eng):
     _compare_em(oo, og)
 
 
+@pytest.mark.parametrize('prec', ['f64', 'f32'])
+def test_em_fused_contraction_of_the_second_mode(pkg, eng, prec):
+    """The EM pass can leave the partial contraction of mode 3 (strip walks mode 3) or of mode 2 (walks mode 2); the
+    update order 1-2-3 always picks mode 3.  With the test hook the other walk is taken: it serves the first mode only
+    (the cache then misses for the second, correctly), so the factors must still match the oracle."""
+    rng = np.random.default_rng(36)
+    Z, io, _ = cp_model((45, 150, 21), 6, rng, [('non-negativity',)] * 3)
+    Z = _with_mask(Z, rng)
+    os.environ['AOADMM_EM_FUSE_SECOND_MODE'] = '1'
+    try:
+        Fo, oo, Fg, og = run_both(pkg, eng, Z, io, options(MaxOuterIters=5), precision=prec)
+    finally:
+        os.environ.pop('AOADMM_EM_FUSE_SECOND_MODE', None)
+    for a, b in zip(Fo['fac'], Fg['fac']):
+        assert rel_fro(b, a) < (1e-4 if prec == 'f32' else 1e-8)
+    assert np.allclose(og['func_rel_missing'][1:], oo['func_rel_missing'][1:], rtol=1e-3 if prec == 'f32' else 1e-7)
+
+
 def test_em_missing_matrix_and_stop_rule(pkg, eng):
     """Matrix block (transposed copy imputed as well) + the extra stopping rule f_rel_missing < OuterRelTol (:457-459)."""
     rng = np.random.default_rng(32)
