@@ -493,7 +493,7 @@ template <int RRMAX>
 __global__ __launch_bounds__(kP2Threads) void par2_b_dual_fold_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
   if (ctl->active == 0) return;
   extern __shared__ double sh2[];         // Dn (RR) | Do (RR) | lane partials [64][RR + 1]
-  __shared__ double red[kP2Threads];
+  __shared__ double red[kP2Threads + 1];   // R*R + 1 totals: R*R = 64 at R = 8
   const int k = d.k0 + blockIdx.x, R = d.R, RR = R * R, W = RR + 1;
   const int lane = threadIdx.x;
   double* Dn = sh2;
@@ -515,10 +515,10 @@ __global__ __launch_bounds__(kP2Threads) void par2_b_dual_fold_k(P2BArgs a, P2Di
       if (e < RR) lp[lane * W + e] = acc[e];
     lp[lane * W + RR] = sr;
     __syncthreads();
-    if (lane <= RR) {                      // lanes in order: the sum does not depend on scheduling
+    for (int col = lane; col <= RR; col += kP2Threads) {   // lanes in order: the sum does not depend on scheduling
       double tot = 0.0;
-      for (int q = 0; q < kP2Threads; ++q) tot += lp[q * W + lane];
-      red[lane] = tot;
+      for (int q = 0; q < kP2Threads; ++q) tot += lp[q * W + col];
+      red[col] = tot;
     }
     __syncthreads();
     if (lane < RR) {

@@ -109,9 +109,9 @@ def par2_slabs(I, Jk, R, rng, noise=0.0, nonneg_C=True):
     return [x / nrm for x in X], A
 
 
-def script4_model(rng, K=12, noise=0.2, constraints_B=None):
+def script4_model(rng, K=12, noise=0.2, constraints_B=None, R=3):
     """example_script4_irregularPAR2.m:18-51: PARAFAC2 I=40, ragged J_k from 61..120, R=3, C non-negative."""
-    I, R = 40, 3
+    I = 40
     Jk = [61 + (7 * k) % 60 for k in range(K)]
     X, _ = par2_slabs(I, Jk, R, rng, noise)
     Z = dict(loss_function=['Frobenius'], model=['PAR2'], modes=[[1, 2, 3]], size=[I, Jk, K],

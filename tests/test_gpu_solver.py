@@ -153,6 +153,16 @@ def test_script4_irregular_parafac2(pkg, eng):
     compare_par2(*run_both(pkg, eng, Z, io, options(MaxOuterIters=12)))
 
 
+@pytest.mark.parametrize('R,K', [(6, 9), (8, 70), (9, 5)])
+def test_parafac2_larger_ranks(pkg, eng, R, K):
+    """The B_k loop with its sums folded into the neighbouring kernels exists for R <= 8 in two register classes (R*R <= 16
+    and <= 64 partial sums per lane; more slabs than lanes at K = 70); R = 9 takes the four-launch form."""
+    from helpers import script4_model
+    rng = np.random.default_rng(13)
+    Z, io = script4_model(rng, K=K, R=R)
+    compare_par2(*run_both(pkg, eng, Z, io, options(MaxOuterIters=6)))
+
+
 def test_parafac2_constrained_Bk(pkg, eng):
     """B_k constrained (example_script9 family: unimodality on the B_k columns, delayed start, rho factor)."""
     from helpers import script4_model
