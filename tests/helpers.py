@@ -39,12 +39,13 @@ def cp_model(dims, R, rng, constraints, noise=0.05, weight=1.0):
     return Z, io, A
 
 
-def script3_model(rng, noise=0.05, rows=50):
+def script3_model(rng, noise=0.05, rows=50, R=4):
     """example_script3_matrix_CP_partialcoupling_nonneg.m:23-68: CP 50x30x40 R=4 + matrix 50x70 R=3,
-    modes 1 and 4 coupled with type 4 (C = Delta*H), H1 = eye(4), H4 = [eye(3); 0 0 0].  `rows`: length of the coupled mode."""
-    D = rng.random((rows, 4))
-    A = [D, rng.standard_normal((30, 4)), rng.standard_normal((40, 4))]
-    M = [D[:, :3], rng.random((70, 3))]
+    modes 1 and 4 coupled with type 4 (C = Delta*H), H1 = eye(4), H4 = [eye(3); 0 0 0].  `rows`: length of the coupled
+    mode; `R`: rank of the tensor (the matrix has one column less)."""
+    D = rng.random((rows, R))
+    A = [D, rng.standard_normal((30, R)), rng.standard_normal((40, R))]
+    M = [D[:, :R - 1], rng.random((70, R - 1))]
     X1 = full_ktensor(A)
     X2 = M[0] @ M[1].T
     for X in (X1, X2):
@@ -53,8 +54,8 @@ def script3_model(rng, noise=0.05, rows=50):
     X1 /= np.linalg.norm(X1)
     X2 /= np.linalg.norm(X2)
     H = [None] * 5
-    H[0] = np.eye(4)
-    H[3] = np.vstack([np.eye(3), np.zeros((1, 3))])
+    H[0] = np.eye(R)
+    H[3] = np.vstack([np.eye(R - 1), np.zeros((1, R - 1))])
     Z = dict(loss_function=['Frobenius'] * 2, model=['CP', 'CP'], modes=[[1, 2, 3], [4, 5]], size=[rows, 30, 40, rows, 70],
              coupling=dict(lin_coupled_modes=[1, 0, 0, 1, 0], coupling_type=[4], coupl_trafo_matrices=H),
              constrained_modes=[1, 0, 0, 1, 1],
@@ -62,13 +63,12 @@ def script3_model(rng, noise=0.05, rows=50):
              weights=[0.5, 0.5], object=[X1, X2])
     distr = [lambda a, b: rng.random((a, b)), lambda a, b: rng.standard_normal((a, b)),
              lambda a, b: rng.standard_normal((a, b)), lambda a, b: rng.random((a, b)), lambda a, b: rng.random((a, b))]
-    io = dict(lambdas_init=[[1, 1, 1, 1], [1, 1, 1]], nvecs=0, distr=distr, normalize=1)
+    io = dict(lambdas_init=[[1] * R, [1] * (R - 1)], nvecs=0, distr=distr, normalize=1)
     return Z, io
 
 
-def cp_cp_exact_model(rng, noise=0.05, rows=24):
+def cp_cp_exact_model(rng, noise=0.05, rows=24, R=3):
     """Two CP tensors sharing their first factor exactly (coupling type 0), non-negative first modes."""
-    R = 3
     D = rng.random((rows, R))
     A = [D, rng.standard_normal((18, R)), rng.random((20, R))]
     B = [D, rng.random((16, R)), rng.standard_normal((14, R))]

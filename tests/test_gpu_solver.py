@@ -79,6 +79,29 @@ def test_cp_cp_exact_coupling(pkg, eng):
     compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=15)))
 
 
+@pytest.mark.parametrize('R', [9, 12, 16])
+def test_short_modes_at_larger_ranks(pkg, eng, R):
+    """The one-workgroup loop of a short mode (admm_loop_wg_k) and the one-launch MTTKRP of a tiny block (small_mttkrp_k)
+    in their widest register class (9 <= R <= 16), with a row-wise, a column-norm and an element-wise prox."""
+    rng = np.random.default_rng(40 + R)
+    Z, io, _ = cp_model((60, 45, 35), R, rng, [('simplex row-wise', 1.0), ('non-negative l2-sphere', 1), ('box', 0.0, 0.6)])
+    compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=6)))
+    Fo, oo, Fg, og = run_both(pkg, eng, Z, io, options(MaxOuterIters=4), precision='f32')
+    for a, b in zip(Fo['fac'], Fg['fac']):
+        assert rel_fro(b, a) < 1e-4
+
+
+@pytest.mark.parametrize('ctype,R', [(0, 6), (0, 8), (4, 7), (4, 8)])
+def test_row_local_coupling_loop_register_classes(pkg, eng, ctype, R):
+    """couple_loop_wg_regs_k with 5..8 rank columns (its second register class), exact coupling and C = Delta*H."""
+    rng = np.random.default_rng(50 + R)
+    if ctype == 0:
+        Z, io = cp_cp_exact_model(rng, rows=57, R=R)
+    else:
+        Z, io = script3_model(rng, rows=57, R=R)
+    compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=6)))
+
+
 @pytest.mark.parametrize('rows', [300, 2500])
 @pytest.mark.parametrize('ctype', [0, 4])
 def test_row_local_coupling_loop_forms(pkg, eng, rows, ctype):
@@ -311,7 +334,9 @@ def test_em_missing_fp32_tensor(pkg, eng):
 
 @pytest.mark.parametrize('dims,R,prec', [((70, 200, 30), 5, 'f64'), ((70, 200, 30), 5, 'f32'),
                                          ((9, 400, 500), 20, 'f32'), ((130, 300), 7, 'f64'),
-                                         ((24, 70, 9), 33, 'f64'), ((24, 70, 9), 33, 'f32')])    # R > 32: one row per thread
+                                         ((24, 70, 9), 33, 'f64'), ((24, 70, 9), 33, 'f32'),     # R > 32: one row per thread
+                                         ((130, 70, 40), 3, 'f32'), ((130, 70, 40), 10, 'f64'), ((130, 70, 40), 14, 'f32'),
+                                         ((130, 70, 40), 18, 'f64'), ((130, 70, 40), 24, 'f32'), ((130, 70, 40), 30, 'f64')])
 def test_em_missing_column_pieces(pkg, eng, dims, R, prec):
     """The EM pass cuts the second mode into pieces of whole 64-column tiles (em.hip: em_chunking): several pieces per
     slab with a short last one, several tiles per piece, a ragged first mode, ranks in different register classes."""
