@@ -102,6 +102,33 @@ def test_row_local_coupling_loop_register_classes(pkg, eng, ctype, R):
     compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=6)))
 
 
+@pytest.mark.parametrize('rows', [40, 300])
+def test_three_blocks_share_a_factor(pkg, eng, rows):
+    """Three CP tensors coupled exactly in their first modes (type 0): the one-workgroup loops with three coupled modes
+    (register form at 40 rows, memory form at 300)."""
+    from oracle.tensor_ops import full_ktensor
+    rng = np.random.default_rng(60 + rows)
+    R = 3
+    D = rng.random((rows, R))
+    shapes = [(14, 11), (9, 16), (12, 10)]
+    objs = []
+    for a, b in shapes:
+        X = full_ktensor([D, rng.random((a, R)), rng.random((b, R))])
+        N = rng.standard_normal(X.shape)
+        X += 0.05 * np.linalg.norm(X) / np.linalg.norm(N) * N
+        objs.append(X / np.linalg.norm(X))
+    size = []
+    for a, b in shapes:
+        size += [rows, a, b]
+    Z = dict(loss_function=['Frobenius'] * 3, model=['CP'] * 3, modes=[[1, 2, 3], [4, 5, 6], [7, 8, 9]], size=size,
+             coupling=dict(lin_coupled_modes=[1, 0, 0, 1, 0, 0, 1, 0, 0], coupling_type=[0], coupl_trafo_matrices=[None] * 9),
+             constrained_modes=[1, 0, 1, 1, 0, 0, 0, 1, 0],
+             constraints=[('non-negativity',), None, ('non-negativity',), ('box', 0.0, 2.0), None, None, None, ('non-negativity',), None],
+             weights=[1 / 3] * 3, object=objs)
+    io = dict(lambdas_init=[[1] * R] * 3, nvecs=0, distr=[lambda a, b: rng.random((a, b))] * 9, normalize=1)
+    compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=8)))
+
+
 @pytest.mark.parametrize('rows', [300, 2500])
 @pytest.mark.parametrize('ctype', [0, 4])
 def test_row_local_coupling_loop_forms(pkg, eng, rows, ctype):
