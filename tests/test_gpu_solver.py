@@ -79,6 +79,15 @@ def test_cp_cp_exact_coupling(pkg, eng):
     compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=15)))
 
 
+@pytest.mark.parametrize('R', [7, 24, 32])
+def test_row_loop_on_the_matrix_cores_rank_classes(pkg, eng, R):
+    """admm_rows_mfma_k (modes longer than 256 rows, element-wise prox) in its smallest, a middle and its largest rank
+    class (R <= 32: eight 4-column steps per row)."""
+    rng = np.random.default_rng(70 + R)
+    Z, io, _ = cp_model((300, 41, 37), R, rng, [('non-negativity',), ('box', 0.0, 0.5), ('l1 regularization', 0.001)])
+    compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=5)))
+
+
 @pytest.mark.parametrize('R', [9, 12, 16])
 def test_short_modes_at_larger_ranks(pkg, eng, R):
     """The one-workgroup loop of a short mode (admm_loop_wg_k) and the one-launch MTTKRP of a tiny block (small_mttkrp_k)

@@ -51,6 +51,11 @@ def one_case(eng, case):
             tol = 2e-4 if prec == 'f32' else 1e-7
             errs = [rel_fro(b, a) for a, b in zip(Fo['fac'], Fg['fac'])]
             ok = all(e < tol for e in errs)
+            # objective values too (they carry the regulariser values of constraints_to_prox.m:50-81)
+            if 'miss' not in Z:
+                ok = ok and np.allclose(og['func_val_conv'], oo['func_val_conv'], rtol=1e-3 if prec == 'f32' else 1e-6, atol=1e-8)
+                if not ok:
+                    errs = errs + ['f: %s vs %s' % (np.asarray(og['func_val_conv'])[-2:], np.asarray(oo['func_val_conv'])[-2:])]
         except Exception as e:
             ok = False
             errs = [repr(e)[:200]]
