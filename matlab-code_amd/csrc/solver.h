@@ -144,6 +144,7 @@ struct TensorInfo {
   double normsq = 0.0;
   bool normsq_valid = false;
   int last_pos = -1;
+  bool eval_shortcut = false;   // PARAFAC2: the enqueued objective evaluation took the last_mttkrp shortcut (:1254-1260)
 };
 
 struct CouplingInfo {

@@ -1411,8 +1411,8 @@ void Engine::prepare_next_first_mode(const aoadmm_options& opt) {
     for (int m = 0; m < n_modes_; ++m) {
       const ModeInfo& mi = modes_[m];
       if (mi.coupling != -1 || mi.tensor != p) continue;
-      if (tensors_[p].par2) return;                 // the first mode updated is a PARAFAC2 mode: nothing ahead
-      prepare_mode_system(m, mi.constrained ? 1 : 0, opt);
+      if (tensors_[p].par2 && mi.pos != 0) return;  // a PARAFAC2 B_k or C mode comes first: nothing ahead
+      prepare_mode_system(m, mi.constrained ? 1 : 0, opt);   // (the first PARAFAC2 mode goes through the same call, :159-178)
       prepared_mode_ = m;
       return;
     }
@@ -2754,7 +2754,8 @@ void Engine::eval_objective_enqueue(bool first) {
                                                  // evaluations reuse the statistics of the EM update pass
     if (t.par2) {
       par2_objective_enqueue(t);                 // direct residual (:1262-1264) + internal-coupling gaps (:1355)
-      if (!masked && !first && t.last_pos == 0) {           // shortcut through last_mttkrp / last_had (:1254-1260)
+      t.eval_shortcut = !masked && !first && t.last_pos == 0;   // remembered for finish_eval: last_pos may move on before
+      if (t.eval_shortcut) {                                // shortcut through last_mttkrp / last_had (:1254-1260)
         ModeInfo& lm = modes_[t.modes[0]];
         double* sp = S + n_modes_ * kSlotsPerMode + 2 * p;
         add(RT_DOT, sp + 0, lm.A.d(), lm.fac.d(), lm.rows * lm.R);
@@ -2895,17 +2896,35 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
     void* p = nullptr; hipEvent_t ev = nullptr;
     ~Pinned() { if (p) (void)hipHostFree(p); if (ev) (void)hipEventDestroy(ev); }
   } pin;
-  AO_HIP(hipHostMalloc(&pin.p, (nslots + 4 * n_tensors_) * sizeof(double) + nctl * sizeof(AdmmCtl), hipHostMallocDefault));
+  // per PARAFAC2 block: K + 1 slab residuals (+ the not-PD flag of sharded slabs), 4 K gap sums, K regulariser values --
+  // read back with everything else behind ONE event (three more copies into pageable memory with a stream
+  // synchronisation each left the GPU idle for ~60 us per outer iteration of config 4)
+  std::vector<size_t> p2off(n_tensors_, 0);
+  size_t p2doubles = 0;
+  for (int p = 0; p < n_tensors_; ++p)
+    if (tensors_[p].par2) { p2off[p] = p2doubles; p2doubles += (size_t)6 * tensors_[p].p2.K + 1; }
+  AO_HIP(hipHostMalloc(&pin.p, (nslots + 4 * n_tensors_ + p2doubles) * sizeof(double) + nctl * sizeof(AdmmCtl), hipHostMallocDefault));
   AO_HIP(hipEventCreateWithFlags(&pin.ev, hipEventDisableTiming));
   double* hs = static_cast<double*>(pin.p);
   double* hem = hs + nslots;                                                   // EM statistics, 4 per tensor
-  AdmmCtl* hctl = reinterpret_cast<AdmmCtl*>(hem + 4 * n_tensors_);
+  double* hp2 = hem + 4 * n_tensors_;                                          // PARAFAC2 per-slab values
+  AdmmCtl* hctl = reinterpret_cast<AdmmCtl*>(hp2 + p2doubles);
 
-  bool eval_first = true;
   auto enqueue_readback = [&]() {
     AO_HIP(hipMemcpyAsync(hs, slots_.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream_));
     AO_HIP(hipMemcpyAsync(hctl, ctls_.p, nctl * sizeof(AdmmCtl), hipMemcpyDeviceToHost, stream_));
     if (has_miss) AO_HIP(hipMemcpyAsync(hem, em_slot(0), 4 * n_tensors_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    for (int p = 0; p < n_tensors_; ++p) {
+      if (!tensors_[p].par2) continue;
+      Par2Block& b = tensors_[p].p2;
+      double* h = hp2 + p2off[p];
+      h[b.K] = 0.0;                                                            // the flag slot exists only with sharded slabs
+      AO_HIP(hipMemcpyAsync(h, b.res.p, (b.K + (b.slab_sharded ? 1 : 0)) * sizeof(double), hipMemcpyDeviceToHost, stream_));
+      AO_HIP(hipMemcpyAsync(h + b.K + 1, b.q.p, (size_t)b.K * 4 * sizeof(double), hipMemcpyDeviceToHost, stream_));
+      const ModeInfo& mB = modes_[tensors_[p].modes[1]];
+      if (mB.constrained && prox_has_reg_value(mB.prox.type))
+        AO_HIP(hipMemcpyAsync(h + 5 * b.K + 1, b.regv.p, b.K * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    }
     AO_HIP(hipEventRecord(pin.ev, stream_));
   };
   auto finish_eval = [&](double f[4]) {
@@ -2921,15 +2940,13 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
       const bool masked = t.par2 ? t.p2.has_mask : t.blk.has_mask;
       if (t.par2) {
         Par2Block& b = t.p2;
-        std::vector<double> res(b.K + 1, 0.0), q((size_t)b.K * 4);
-        AO_HIP(hipMemcpyAsync(res.data(), b.res.p, (b.K + (b.slab_sharded ? 1 : 0)) * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        AO_HIP(hipMemcpyAsync(q.data(), b.q.p, (size_t)b.K * 4 * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        AO_HIP(hipStreamSynchronize(stream_));
+        const double* res = hp2 + p2off[p];
+        const double* q = res + b.K + 1;
         if (res[b.K] > 0)                           // some rank's slabs hit a non-positive-definite system
           throw Error(AOADMM_ERR_NOT_PD, "Cholesky failed in a PARAFAC2 slab system on another rank (chol in cmtf_fun_AOADMM.m:212/240)");
         double fp = 0.0;
         if (masked) fp = hem[4 * p + 2];                                                        // :1249-1252
-        else if (!eval_first && t.last_pos == 0) fp = t.normsq - 2.0 * (sp[0] / t.weight) + sp[1];   // :1254-1260
+        else if (t.eval_shortcut) fp = t.normsq - 2.0 * (sp[0] / t.weight) + sp[1];               // :1254-1260
         else for (int k = 0; k < b.K; ++k) fp += res[k];                                        // :1262-1264
         ft += t.weight * fp;                                                                    // :1267
         const ModeInfo& mB = modes_[t.modes[1]];
@@ -2947,9 +2964,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
           ft += mB.prox.p0 * pen;
         }
         if (mB.constrained && prox_has_reg_value(mB.prox.type)) {          // sum_k reg_func(B_k) (:1279-1281)
-          std::vector<double> rv(b.K);
-          AO_HIP(hipMemcpyAsync(rv.data(), b.regv.p, b.K * sizeof(double), hipMemcpyDeviceToHost, stream_));
-          AO_HIP(hipStreamSynchronize(stream_));
+          const double* rv = res + 5 * b.K + 1;
           for (int k = 0; k < b.K; ++k) ft += rv[k];
         }
         if (mB.constrained) {
@@ -3000,7 +3015,6 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   eval_objective_enqueue(true);                                                // :32
   enqueue_readback();
   finish_eval(f);
-  eval_first = false;
   if (out->func_val_conv) out->func_val_conv[0] = f[0];
   if (out->func_coupl_conv) out->func_coupl_conv[0] = f[1];
   if (out->func_constr_conv) out->func_constr_conv[0] = f[2];

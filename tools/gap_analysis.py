@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Idle time between kernels in the steady state of a rocprofv3 kernel trace of bench.py (development tool).
-usage: gap_analysis.py <kernel_trace.csv> [skip_first_passes]"""
+usage: gap_analysis.py <kernel_trace.csv> [skip_first_markers] [marker-kernel-substring]  (marker: a kernel that runs once or a
+fixed number of times per outer iteration; default the contraction passes)"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+marker = sys.argv[3] if len(sys.argv) > 3 else 'contract'
 ev = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0]) for r in rows), key=lambda e: e[0])
-passes = [i for i, e in enumerate(ev) if 'contract16_f32' in e[2] or 'contract_f64' in e[2]]
+passes = [i for i, e in enumerate(ev) if marker in e[2]]
 if len(passes) < skip + 4:
     sys.exit('too few passes')
 lo, hi = passes[skip], passes[-4]
@@ -19,7 +21,7 @@ for st, en, name in seg:
         idle.append((st - cur_end, prev_name, name))
     if en > cur_end:
         cur_end, prev_name = en, name
-npass = sum(1 for e in seg[:-1] if 'contract' in e[2])
+npass = sum(1 for e in seg[:-1] if marker in e[2])
 tot_idle = sum(g[0] for g in idle)
 print('window: %d kernels, %d passes, span %.3f ms, no kernel running for %.3f ms = %.1f us per pass-to-pass interval'
       % (len(seg) - 1, npass, (t1 - t0) / 1e6, tot_idle / 1e6, tot_idle / 1e3 / max(npass, 1)))
