@@ -503,12 +503,27 @@ __global__ __launch_bounds__(kP2Threads) void par2_b_dual_fold_k(P2BArgs a, P2Di
     double acc[RRMAX], sr = 0.0;
 #pragma unroll
     for (int e = 0; e < RRMAX; ++e) acc[e] = 0.0;
-    for (int kk = d.k0 + lane; kk < d.k1; kk += kP2Threads) {
-      const double* pk = a.part + (int64_t)kk * RR;
+    // UB slabs per step, their loads issued before the first addition (one slab per step was one L2 round trip per
+    // 64 slabs, in sequence); added in slab order
+    constexpr int UB = RRMAX <= 16 ? 4 : 2;
+    for (int kk = d.k0 + lane; kk < d.k1; kk += UB * kP2Threads) {
+      double v[UB][RRMAX], rv[UB];
 #pragma unroll
-      for (int e = 0; e < RRMAX; ++e)
-        if (e < RR) acc[e] += pk[e];
-      sr += a.rho[kk];
+      for (int u = 0; u < UB; ++u) {
+        const int ku = kk + u * kP2Threads;
+        const double* pk = a.part + (int64_t)(ku < d.k1 ? ku : kk) * RR;
+#pragma unroll
+        for (int e = 0; e < RRMAX; ++e) v[u][e] = e < RR ? pk[e] : 0.0;
+        rv[u] = a.rho[ku < d.k1 ? ku : kk];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        if (kk + u * kP2Threads < d.k1) {
+#pragma unroll
+          for (int e = 0; e < RRMAX; ++e) acc[e] += v[u][e];
+          sr += rv[u];
+        }
+      }
     }
 #pragma unroll
     for (int e = 0; e < RRMAX; ++e)
@@ -533,17 +548,30 @@ __global__ __launch_bounds__(kP2Threads) void par2_b_dual_fold_k(P2BArgs a, P2Di
   const int Jk = (int)(d.off[k + 1] - o);
   const int64_t base = o * R;
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  for (int e = threadIdx.x; e < Jk * R; e += blockDim.x) {
-    const int j = e % Jk, r = e / Jk;
-    double pd = 0.0, po = 0.0;
+  // two entries per step: the loads of both are in flight together
+  const int ne = Jk * R, st = blockDim.x;
+  for (int e = threadIdx.x; e < ne; e += 2 * st) {
+    const int e1 = e + st;
+    const bool two = e1 < ne;
+    const int e1c = two ? e1 : e;
+    const int j0 = e % Jk, r0 = e / Jk, j1 = e1c % Jk, r1 = e1c / Jk;
+    double pd0 = 0.0, po0 = 0.0, pd1 = 0.0, po1 = 0.0;
     for (int q = 0; q < R; ++q) {
-      pd += a.P[base + j + Jk * q] * Dn[q + R * r];
-      po += a.Pold[base + j + Jk * q] * Do[q + R * r];
+      const double p0 = a.P[base + j0 + Jk * q], o0 = a.Pold[base + j0 + Jk * q];
+      const double p1 = a.P[base + j1 + Jk * q], o1 = a.Pold[base + j1 + Jk * q];
+      pd0 += p0 * Dn[q + R * r0]; po0 += o0 * Do[q + R * r0];
+      pd1 += p1 * Dn[q + R * r1]; po1 += o1 * Do[q + R * r1];
     }
-    const double b = a.B[base + e];
-    const double m = a.mu[base + e] + b - pd;                                   // :546
-    a.mu[base + e] = m;
-    s0 += (b - pd) * (b - pd); s1 += b * b; s2 += (po - pd) * (po - pd); s3 += m * m;
+    const double b0 = a.B[base + e], b1 = a.B[base + e1c];
+    const double mo0 = a.mu[base + e], mo1 = a.mu[base + e1c];
+    const double m0 = mo0 + b0 - pd0;                                            // :546
+    a.mu[base + e] = m0;
+    s0 += (b0 - pd0) * (b0 - pd0); s1 += b0 * b0; s2 += (po0 - pd0) * (po0 - pd0); s3 += m0 * m0;
+    if (two) {
+      const double m1 = mo1 + b1 - pd1;
+      a.mu[base + e1] = m1;
+      s0 += (b1 - pd1) * (b1 - pd1); s1 += b1 * b1; s2 += (po1 - pd1) * (po1 - pd1); s3 += m1 * m1;
+    }
   }
   s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
   if (threadIdx.x == 0) {
