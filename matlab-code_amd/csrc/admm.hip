@@ -764,12 +764,20 @@ struct TvFused {
 // kTvThreads threads per column (256 for short columns, 1024 above 1024 rows: every phase walks a thread's chunk of
 // ceil(n / kTvThreads) entries sequentially through LDS, so four times the threads is close to four times fewer
 // dependent LDS round trips; measured at 2000 rows in DESIGN.md section 4.4).
-template <int kTvThreads>
+// GLOBAL: columns beyond kTvParMax rows keep the same working arrays in a per-column slice of the prox workspace
+// (L2-resident: 37 bytes per row) instead of LDS, so a long mode does not drop to the one-thread scan; the index field
+// of the split key widens to 24 bits.
+static __host__ __device__ inline size_t tv_ws_doubles(int64_t rows) {
+  return ((size_t)(4 * rows + 2) * 8 + (size_t)(rows + 2) * 4 + (size_t)rows + 64 + 7) / 8;
+}
+template <int kTvThreads, bool GLOBAL = false>
 __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const double* warm, int64_t ldw, TvFused fz,
                                                              const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
   constexpr int NW = kTvThreads / 64;
-  extern __shared__ double dyn[];
+  constexpr unsigned long long kIdxMask = GLOBAL ? 0xffffffull : 0xfffull;
+  extern __shared__ double lds_dyn[];
+  double* dyn = GLOBAL ? a.ws + (size_t)blockIdx.x * tv_ws_doubles(a.rows) : lds_dyn;
   __shared__ int wsum[NW];
   __shared__ double dsum[NW];
   __shared__ int flag_merge, flag_split;
@@ -809,7 +817,22 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
         if (i < n) { y[i] = ry[k]; val[i] = rw[k]; }
       }
     };
-    if (n <= kTvThreads) stage(std::integral_constant<int, 1>());
+    if constexpr (GLOBAL) {
+      for (int i0 = 0; i0 < n; i0 += 8 * kTvThreads) {  // eight independent loads of each column per round trip
+        double ry[8], rw[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = min(i0 + t + k * kTvThreads, n - 1);
+          ry[k] = vin[i];
+          rw[k] = wv[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = i0 + t + k * kTvThreads;
+          if (i < n) { y[i] = ry[k]; val[i] = rw[k]; }
+        }
+      }
+    } else if (n <= kTvThreads) stage(std::integral_constant<int, 1>());
     else if (n <= 2 * kTvThreads) stage(std::integral_constant<int, 2>());
     else if (n <= 4 * kTvThreads) stage(std::integral_constant<int, 4>());
     else if (n <= 8 * kTvThreads) stage(std::integral_constant<int, 8>());
@@ -907,7 +930,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
           const double u = u0 + (Pc[i + 1] - Pc[sa]) - (val[sgi] - c) * (double)(i - sa + 1);
           const double au = fabs(u);
           if (au > thr) {
-            const unsigned long long key = ((unsigned long long)__double_as_longlong(au) & ~0xfffull) | (unsigned long long)i;
+            const unsigned long long key = ((unsigned long long)__double_as_longlong(au) & ~kIdxMask) | (unsigned long long)i;
             atomicMax(&best[sgi], key);
           }
         }
@@ -916,7 +939,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
       for (int sgi = t; sgi < nseg; sgi += kTvThreads) {
         const unsigned long long b = best[sgi];
         if (b != 0ull) {
-          const int i = (int)(b & 0xfffull);
+          const int i = (int)(b & kIdxMask);
           const int sa = start[sgi];
           const double u0 = sa == 0 ? 0.0 : -lam * (double)J[sa - 1];
           const double u = u0 + (Pc[i + 1] - Pc[sa]) - (val[sgi] - c) * (double)(i - sa + 1);
@@ -987,7 +1010,30 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
       }
     }
   };
-  if (n <= kTvThreads) dual(std::integral_constant<int, 1>());
+  if constexpr (GLOBAL) {
+    for (int i0 = 0; i0 < n; i0 += 4 * kTvThreads) {
+      double mo[4], zo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = min(i0 + t + k * kTvThreads, n - 1);
+        mo[k] = muc[i];
+        zo[k] = Zc[i];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + t + k * kTvThreads;
+        if (i < n) {
+          const double zn = val[i], vv = y[i];
+          const double x = vv - mo[k];
+          const double mn = vv - zn;
+          Zc[i] = zn;
+          muc[i] = mn;
+          const double d = x - zn, e = zn - zo[k];
+          s1 += d * d; s2 += x * x; s3 += mn * mn; s4 += e * e;
+        }
+      }
+    }
+  } else if (n <= kTvThreads) dual(std::integral_constant<int, 1>());
   else if (n <= 2 * kTvThreads) dual(std::integral_constant<int, 2>());
   else if (n <= 4 * kTvThreads) dual(std::integral_constant<int, 4>());
   else if (n <= 8 * kTvThreads) dual(std::integral_constant<int, 8>());
@@ -1156,6 +1202,7 @@ size_t prox_ws_bytes(int type, int64_t rows, int R) {
     case AOADMM_C_GL_SMOOTH: return (size_t)R * rows * sizeof(double);
     case AOADMM_C_ORTHONORMAL: return ortho_ws_doubles(rows, R) * sizeof(double);
     case AOADMM_C_QUADRATIC: return (size_t)R * rows * sizeof(double);
+    case AOADMM_C_TV: return rows > kTvParMax ? (size_t)R * tv_ws_doubles(rows) * sizeof(double) : 16;
     default: return 16;
   }
 }
@@ -1163,7 +1210,11 @@ size_t prox_ws_bytes(int type, int64_t rows, int R) {
 static size_t tv_fast_lds(int64_t rows) { return (size_t)(4 * rows + 2) * 8 + (size_t)(rows + 2) * 4 + (size_t)rows + 64; }
 static void tv_fast_launch(const ColArgs& a, const double* warm, int64_t ldw, const TvFused& fz, const AdmmCtl* ctl,
                            hipStream_t s) {
-  if (a.rows > 1024) {
+  if (a.rows > kTvParMax) {
+    AO_REQUIRE(a.ws != nullptr && a.rows < (int64_t(1) << 24), "TV prox: %lld rows need the global workspace (below 2^24 rows)",
+               (long long)a.rows);
+    prox_tv_fast_k<1024, true><<<a.R, 1024, 0, s>>>(a, warm, ldw, fz, ctl);
+  } else if (a.rows > 1024) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(prox_tv_fast_k<1024>), (int)tv_fast_lds(kTvParMax));
     prox_tv_fast_k<1024><<<a.R, 1024, tv_fast_lds(a.rows), s>>>(a, warm, ldw, fz, ctl);
   } else {
@@ -1196,7 +1247,8 @@ void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, 
       prox_simplex_col_k<<<R, 256, 0, s>>>(a, ctl);
       break;
     case AOADMM_C_TV: {
-      if (rows <= kTvParMax) {
+      static const bool seq_long = getenv("AOADMM_TV_SEQ_LONG") != nullptr;     // development switch: one-thread scan beyond 4096 rows
+      if (rows <= kTvParMax || (!seq_long && ws != nullptr && rows < (int64_t(1) << 24))) {   // LDS-resident, or the same in the workspace
         tv_fast_launch(a, warm, ldw, TvFused(), ctl, s);
         break;
       }
@@ -1570,7 +1622,8 @@ void admm_constrained_loop(const AdmmMode& m, double* part, double* V, double* Z
     if (deferred_end) *deferred_end = LoopEnd();    // the loop is closed: pass 2 recorded iters / residuals
     return;
   }
-  const bool tv_fused = !a.fused && m.prox.type == AOADMM_C_TV && m.rows <= kTvParMax;   // prox + dual in one kernel
+  const bool tv_fused = !a.fused && m.prox.type == AOADMM_C_TV &&                        // prox + dual in one kernel
+                        (m.rows <= kTvParMax || (prox_ws != nullptr && m.rows < (int64_t(1) << 24)));
   const int nparts = a.fused ? (int)blocks : (tv_fused ? m.R : (int)nbd);
   for (int it = 0; it < max_inner; ++it) {
     a.it = it;

@@ -76,6 +76,31 @@ def test_prox_matches_oracle(eng, c, shape):
     assert rel_fro(got, ref) < 1e-10 or np.max(np.abs(got - ref)) < 1e-12, rel_fro(got, ref)
 
 
+@pytest.mark.parametrize('kind', ['noise', 'steps', 'constant', 'ramp', 'strong'])
+@pytest.mark.parametrize('rows', [4097, 9000, 20011])
+def test_tv_prox_long_columns(eng, kind, rows):
+    """TV beyond the LDS-resident 4096 rows: the same parallel split/merge active set with its working arrays in the
+    prox workspace (prox_tv_fast_k<1024, true>) instead of the one-thread scan; exact, like the short-column kernel."""
+    rng = np.random.default_rng(rows + zlib.crc32(kind.encode()) % 1000)
+    R = 3
+    if kind == 'noise':
+        X, eta = rng.standard_normal((rows, R)), 0.4
+    elif kind == 'steps':
+        X = np.repeat(rng.standard_normal((rows // 500 + 1, R)), 500, axis=0)[:rows] + 0.05 * rng.standard_normal((rows, R))
+        eta = 0.3
+    elif kind == 'constant':
+        X, eta = np.full((rows, R), 1.25), 0.4
+    elif kind == 'ramp':
+        X, eta = np.linspace(-1, 1, rows)[:, None] * np.array([[1.0, -2.0, 0.5]]), 0.01
+    else:                                               # one segment: the whole column merges to its mean
+        X, eta = rng.standard_normal((rows, R)), 1e4
+    c = ('TV regularization', eta)
+    ops, _ = OP.constraints_to_prox([1], [c], [rows])
+    ref = ops[0](X, 1.7)
+    got = eng.prox(c, X, 1.7)
+    assert rel_fro(got, ref) < 1e-10 or np.max(np.abs(got - ref)) < 1e-12, rel_fro(got, ref)
+
+
 SHAPE_CASES = [('non-decreasing',), ('non-increasing',), ('unimodality', True), ('unimodality', False), ('GL smoothness', 0.7)]
 
 

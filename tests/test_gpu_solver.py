@@ -59,6 +59,14 @@ def test_cp_tv_nonneg(pkg, eng):
     compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=15)))
 
 
+def test_cp_tv_long_mode(pkg, eng):
+    """TV on a mode longer than the LDS-resident 4096 rows: the in-loop kernel (prox + dual update + residual sums,
+    warm-started from the previous Z) with its working arrays in the prox workspace."""
+    rng = np.random.default_rng(12)
+    Z, io, _ = cp_model((4500, 9, 8), 3, rng, [('TV regularization', 0.01), ('non-negativity',), ('non-negativity',)])
+    compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=6)))
+
+
 def test_cp_mixed_constraints_and_ls(pkg, eng):
     rng = np.random.default_rng(3)
     Z, io, _ = cp_model((30, 25, 20), 4, rng, [None, ('l2-ball', 1.0), ('unimodality', True)])
