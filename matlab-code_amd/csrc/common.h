@@ -46,19 +46,26 @@ inline std::string fmt(const char* f, ...) {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool owned = true;                 // false: a view into another buffer (see view())
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned) { o.p = nullptr; o.bytes = 0; o.owned = true; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; owned = o.owned; o.p = nullptr; o.bytes = 0; o.owned = true; }
     return *this;
   }
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
+    owned = true;
+  }
+  // n bytes at ptr inside a buffer someone else owns and outlives this one (ensure() up to n bytes keeps the view)
+  void view(void* ptr, size_t n) {
+    release();
+    p = ptr; bytes = n; owned = false;
   }
   void alloc(size_t n) {
     release();

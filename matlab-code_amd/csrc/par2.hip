@@ -141,6 +141,11 @@ __global__ void par2_b_system_k(const double* GA, const double* Cfac, double w, 
   extern __shared__ double sh[];
   __shared__ double rk;
   const int k = d.k0 + blockIdx.x, R = d.R;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && ctl) {                    // opens the B_k loop (what ctl_reset does; notpd stays)
+    ctl->active = 1;
+    ctl->iters = 0;
+    ctl->res[0] = ctl->res[1] = ctl->res[2] = ctl->res[3] = 0.0;
+  }
   for (int e = threadIdx.x; e < R * R; e += blockDim.x) {
     const int r = e % R, q = e / R;
     sh[e] = Cfac[k + d.K * r] * GA[e] * Cfac[k + d.K * q];           // C_k = D_k (A'A) D_k   (:194)

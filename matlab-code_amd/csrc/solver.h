@@ -278,6 +278,8 @@ class Engine {
   std::vector<ModeInfo> modes_;
   std::vector<TensorInfo> tensors_;
   std::vector<CouplingInfo> couplings_;
+  DevBuf readback_;      // everything the host reads once per outer iteration, in one piece (one copy): slots_ | ctls_ |
+                         // per PARAFAC2 block res (K + 1), q (4 K), regv (K); the three below are views into it
   DevBuf ctls_;          // AdmmCtl[n_modes + n_couplings]
   DevBuf slots_;         // objective scalars
   DevBuf redws_;         // reduction workspace

@@ -452,10 +452,32 @@ void Engine::model_end() {
       }
     }
   }
-  ctls_.alloc((size_t)(n_modes_ + n_couplings_ + 1) * sizeof(AdmmCtl));
-  AO_HIP(hipMemsetAsync(ctls_.p, 0, ctls_.bytes, stream_));
-  slots_.alloc((size_t)(n_modes_ * (kSlotsPerMode + kResidPerMode) + 2 * n_tensors_ + 16 + 4 * n_tensors_) * sizeof(double));
-  AO_HIP(hipMemsetAsync(slots_.p, 0, slots_.bytes, stream_));
+  {
+    // one arena for what the host reads back per outer iteration, so that one copy fetches it
+    const size_t nsl = (size_t)(n_modes_ * (kSlotsPerMode + kResidPerMode) + 2 * n_tensors_ + 16 + 4 * n_tensors_) * sizeof(double);
+    const size_t nct = (size_t)(n_modes_ + n_couplings_ + 1) * sizeof(AdmmCtl);
+    const size_t off_ctl = (size_t)round_up((int64_t)nsl, 64);
+    size_t tot = (size_t)round_up((int64_t)(off_ctl + nct), 64);
+    std::vector<size_t> off_p2(n_tensors_, 0);
+    for (int p = 0; p < n_tensors_; ++p)
+      if (tensors_[p].par2) { off_p2[p] = tot; tot += ((size_t)6 * tensors_[p].p2.K + 1) * sizeof(double); }
+    for (int p = 0; p < n_tensors_; ++p)            // views of the previous arena go before it does
+      if (tensors_[p].par2) { tensors_[p].p2.res.release(); tensors_[p].p2.q.release(); tensors_[p].p2.regv.release(); }
+    ctls_.release(); slots_.release();
+    readback_.alloc(tot);
+    AO_HIP(hipMemsetAsync(readback_.p, 0, readback_.bytes, stream_));
+    char* base = readback_.as<char>();
+    slots_.view(base, nsl);
+    ctls_.view(base + off_ctl, nct);
+    for (int p = 0; p < n_tensors_; ++p) {
+      if (!tensors_[p].par2) continue;
+      Par2Block& b = tensors_[p].p2;
+      char* q = base + off_p2[p];
+      b.res.view(q, (size_t)(b.K + 1) * 8);
+      b.q.view(q + (size_t)(b.K + 1) * 8, (size_t)b.K * 4 * 8);
+      b.regv.view(q + (size_t)(5 * b.K + 1) * 8, (size_t)b.K * 8);
+    }
+  }
   AO_HIP(hipStreamSynchronize(stream_));
   model_done_ = true;
 }
@@ -1502,8 +1524,13 @@ static const double* adjoint_f(double* dst, const CouplingInfo& ci, const double
   return Y;
 }
 
-__global__ void coupling_coefs_k(double* coef, const double* const* rhos, int n) {
-  // coef[j] = rho_j / sum rho  (:661-675)
+__global__ void coupling_coefs_k(double* coef, const double* const* rhos, int n, AdmmCtl* ctl) {
+  // coef[j] = rho_j / sum rho  (:661-675); also opens the coupled loop (what ctl_reset does: one launch fewer)
+  if (threadIdx.x == 1) {
+    ctl->active = 1;
+    ctl->iters = 0;
+    ctl->res[0] = ctl->res[1] = ctl->res[2] = ctl->res[3] = 0.0;
+  }
   if (threadIdx.x == 0) {
     double s = 0.0;
     for (int j = 0; j < n; ++j) s += rhos[j][0];
@@ -2387,8 +2414,8 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
     const size_t nimg = (size_t)std::max(mi.rows * mi.R, mi.img_rows * mi.img_cols) * sizeof(double);
     mi.TD.ensure(nimg); mi.TF.ensure(nimg); mi.tmp.ensure(nimg); mi.W1.ensure(nimg); mi.W2.ensure(nimg);
   }
-  // reset the loop control (the per-mode sys_build calls reset their own blocks)
-  ctl_reset(ctl, stream_);
+  // reset the loop control (the per-mode sys_build calls reset their own blocks); types 0-2: in coupling_coefs_k below
+  if (!(ty == 0 || ty == 1 || ty == 2)) ctl_reset(ctl, stream_);
   // per-outer-iteration constants
   std::vector<const double*> hp(n);
   bool any_pc = false;                                // a PARAFAC2 C mode in this coupling (types 0 and 1 only)
@@ -2410,7 +2437,7 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
   }
   const double* rho_last = modes_[ci.modes[n - 1]].rho.d();   // type 5: rhoC = mean(rho{mm}) with the stale loop variable (:1032)
   if (ty == 0 || ty == 1 || ty == 2) {
-    coupling_coefs_k<<<1, 64, 0, stream_>>>(ci.coef.d(), rho_ptrs.as<const double*>(), n);
+    coupling_coefs_k<<<1, 64, 0, stream_>>>(ci.coef.d(), rho_ptrs.as<const double*>(), n, ctl);
     AO_KERNEL_CHECK();
   } else if (ty == 4 || ty == 5) {
     AAArgs aa, aaa;                                   // aaa: the PARAFAC2 C mode's H*H' kept apart (:946-948)
@@ -2899,32 +2926,29 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   // per PARAFAC2 block: K + 1 slab residuals (+ the not-PD flag of sharded slabs), 4 K gap sums, K regulariser values --
   // read back with everything else behind ONE event (three more copies into pageable memory with a stream
   // synchronisation each left the GPU idle for ~60 us per outer iteration of config 4)
-  std::vector<size_t> p2off(n_tensors_, 0);
-  size_t p2doubles = 0;
-  for (int p = 0; p < n_tensors_; ++p)
-    if (tensors_[p].par2) { p2off[p] = p2doubles; p2doubles += (size_t)6 * tensors_[p].p2.K + 1; }
-  AO_HIP(hipHostMalloc(&pin.p, (nslots + 4 * n_tensors_ + p2doubles) * sizeof(double) + nctl * sizeof(AdmmCtl), hipHostMallocDefault));
+  const char* rb_base = readback_.as<char>();
+  auto in_arena = [&](const DevBuf& d) {
+    return !d.owned && static_cast<const char*>(d.p) >= rb_base && static_cast<const char*>(d.p) + d.bytes <= rb_base + readback_.bytes;
+  };
+  AO_REQUIRE(in_arena(slots_) && in_arena(ctls_), "read-back arena: slots / loop-control blocks are not views of it");
+  AO_HIP(hipHostMalloc(&pin.p, readback_.bytes, hipHostMallocDefault));
   AO_HIP(hipEventCreateWithFlags(&pin.ev, hipEventDisableTiming));
-  double* hs = static_cast<double*>(pin.p);
-  double* hem = hs + nslots;                                                   // EM statistics, 4 per tensor
-  double* hp2 = hem + 4 * n_tensors_;                                          // PARAFAC2 per-slab values
-  AdmmCtl* hctl = reinterpret_cast<AdmmCtl*>(hp2 + p2doubles);
+  char* hb = static_cast<char*>(pin.p);
+  double* hs = reinterpret_cast<double*>(hb + (slots_.as<char>() - rb_base));
+  double* hem = hs + (em_slot(0) - slots_.d());                                // EM statistics, 4 per tensor
+  AdmmCtl* hctl = reinterpret_cast<AdmmCtl*>(hb + (ctls_.as<char>() - rb_base));
+  std::vector<double*> hp2v(n_tensors_, nullptr);                              // PARAFAC2 per-slab values: res | q | regv
+  for (int p = 0; p < n_tensors_; ++p) {
+    if (!tensors_[p].par2) continue;
+    Par2Block& b = tensors_[p].p2;
+    AO_REQUIRE(in_arena(b.res) && in_arena(b.q) && in_arena(b.regv) && b.q.d() == b.res.d() + b.K + 1 &&
+               b.regv.d() == b.res.d() + 5 * b.K + 1, "read-back arena: PARAFAC2 block %d keeps its sums elsewhere", p);
+    hp2v[p] = reinterpret_cast<double*>(hb + (b.res.as<char>() - rb_base));
+  }
+  (void)nslots;
 
   auto enqueue_readback = [&]() {
-    AO_HIP(hipMemcpyAsync(hs, slots_.p, nslots * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    AO_HIP(hipMemcpyAsync(hctl, ctls_.p, nctl * sizeof(AdmmCtl), hipMemcpyDeviceToHost, stream_));
-    if (has_miss) AO_HIP(hipMemcpyAsync(hem, em_slot(0), 4 * n_tensors_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    for (int p = 0; p < n_tensors_; ++p) {
-      if (!tensors_[p].par2) continue;
-      Par2Block& b = tensors_[p].p2;
-      double* h = hp2 + p2off[p];
-      h[b.K] = 0.0;                                                            // the flag slot exists only with sharded slabs
-      AO_HIP(hipMemcpyAsync(h, b.res.p, (b.K + (b.slab_sharded ? 1 : 0)) * sizeof(double), hipMemcpyDeviceToHost, stream_));
-      AO_HIP(hipMemcpyAsync(h + b.K + 1, b.q.p, (size_t)b.K * 4 * sizeof(double), hipMemcpyDeviceToHost, stream_));
-      const ModeInfo& mB = modes_[tensors_[p].modes[1]];
-      if (mB.constrained && prox_has_reg_value(mB.prox.type))
-        AO_HIP(hipMemcpyAsync(h + 5 * b.K + 1, b.regv.p, b.K * sizeof(double), hipMemcpyDeviceToHost, stream_));
-    }
+    AO_HIP(hipMemcpyAsync(hb, readback_.p, readback_.bytes, hipMemcpyDeviceToHost, stream_));
     AO_HIP(hipEventRecord(pin.ev, stream_));
   };
   auto finish_eval = [&](double f[4]) {
@@ -2940,7 +2964,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
       const bool masked = t.par2 ? t.p2.has_mask : t.blk.has_mask;
       if (t.par2) {
         Par2Block& b = t.p2;
-        const double* res = hp2 + p2off[p];
+        const double* res = hp2v[p];
         const double* q = res + b.K + 1;
         if (res[b.K] > 0)                           // some rank's slabs hit a non-positive-definite system
           throw Error(AOADMM_ERR_NOT_PD, "Cholesky failed in a PARAFAC2 slab system on another rank (chol in cmtf_fun_AOADMM.m:212/240)");

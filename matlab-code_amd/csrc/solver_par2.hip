@@ -169,8 +169,7 @@ void Engine::par2_update_B(int m, const aoadmm_options& opt, int iter) {
     const double* x[2] = {b.Ak.d(), mi.fac.d()};
     ew_lincomb(b.Ak.d(), b.Jtot * b.R, 2, c, x, nullptr, stream_);
   }
-  t.last_pos = 1;                                                                        // last_m(p) = 2
-  ctl_reset(ctl, stream_);
+  t.last_pos = 1;                                                                        // last_m(p) = 2; par2_b_system opened the loop (ctl)
   P2BArgs a;
   a.Ak = b.Ak.d(); a.L = b.Lk.d(); a.rho = b.rhok.d();
   a.B = mi.fac.d(); a.P = b.P.d(); a.Pold = b.Pold.d(); a.mu = b.muDB.d(); a.W = b.W.d();
