@@ -27,6 +27,9 @@ done
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pp -- python3 $R/tools/time_prox.py > /dev/null 2>&1
 find $OUT/pp -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/r02_prox_kernel_stats.csv
 rm -rf $OUT/pp
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pt -- python3 $R/tools/time_tv_long.py > /dev/null 2>&1
+find $OUT/pt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/r02_tv_long_kernel_stats.csv
+rm -rf $OUT/pt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pe -- python3 $R/tools/time_em.py > $OUT/r02_em_timing.txt 2>&1
 find $OUT/pe -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/r02_em_kernel_stats.csv
 rm -rf $OUT/pe

@@ -26,10 +26,11 @@ def cfg2_model(rng):
 
 def slope(eng, Z, G, n1, n2, precision='f64'):
     t = {}
-    for n in (n1, n1, n2):                      # the first solve also pays one-time allocations
+    for n in (n1, n1, n2, n1, n2, n1, n2):      # the first solve also pays one-time allocations; fastest of three each
         t0 = time.perf_counter()
         pkg.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=n), init=copy.deepcopy(G), engine=eng, precision=precision)
-        t[n] = time.perf_counter() - t0
+        dt = time.perf_counter() - t0
+        t[n] = min(t.get(n, dt), dt)
     return (t[n2] - t[n1]) / (n2 - n1) * 1e3, t[n2]
 
 
