@@ -1,6 +1,7 @@
 // ADMM inner-loop kernels and the proximal operator catalogue
 // (functions/cmtf_fun_AOADMM.m:591-623,1420-1429 ; functions/constraints_to_prox.m:13-91).
 #pragma once
+#include <vector>
 #include "common.h"
 #include "small.h"
 #include "loopctl.h"
@@ -15,16 +16,30 @@ struct ProxSpec {
   const double* LU = nullptr;
   const double* LUt = nullptr;
   const double* Lw = nullptr;
+  struct QuadPrep* quad = nullptr; // non-symmetric L: the prox refreshes (2*eta/rho*L + I)^-1 through it when rho moved
 };
 
 // 'quadratic regularization' (constraints_to_prox.m:62-67): prox(x,rho) = (2*eta/rho*L + I) \ x with a fixed
 // user matrix L.  rho changes every outer iteration, L does not: L is diagonalised once on the host
 // (symmetric L required) and the prox becomes U * diag(1/(2*eta/rho*w_i + 1)) * U' * x, two small GEMMs.
+// A non-symmetric L has no orthogonal eigenbasis: the host keeps L, and whenever 2*eta/rho differs from the value
+// the cached inverse was built for (once per outer iteration: rho is fixed inside an inner loop) it inverts
+// 2*eta/rho*L + I by Gauss-Jordan elimination with partial pivoting (what MATLAB's `\` pivots on) and uploads the
+// inverse; the prox is then one small GEMM.  The reference factorises the same matrix in EVERY prox call.
 struct QuadPrep {
   DevBuf L, U, Ut, w;
+  DevBuf Minv;                     // non-symmetric L: (g*L + I)^-1, column-major
+  std::vector<double> Lh;          // non-symmetric L: host copy (column-major, as passed)
+  bool nonsym = false;
+  double g_cached = -1.0;
   int64_t n = 0;
   void build(const double* L_host, int64_t rows, hipStream_t s);
-  void attach(ProxSpec& ps) const { ps.Lmat = L.d(); ps.LU = U.d(); ps.LUt = Ut.d(); ps.Lw = w.d(); }
+  void attach(ProxSpec& ps) {
+    ps.Lmat = L.d(); ps.LU = U.d(); ps.LUt = Ut.d(); ps.Lw = w.d();
+    ps.quad = nonsym ? this : nullptr;
+  }
+  // reads rho from the device (a stream synchronisation), rebuilds Minv if g = 2*eta/(rho*rho_mul) changed
+  const double* refresh(double eta, const double* rho_dev, double rho_mul, hipStream_t s);
 };
 
 // iso.hip: workgroup-parallel isotonic / unimodal projections and the path-Laplacian smoothness prox

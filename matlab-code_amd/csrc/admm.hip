@@ -1167,20 +1167,80 @@ void QuadPrep::build(const double* L_host, int64_t rows, hipStream_t s) {
       const double d = A[(size_t)i + (size_t)rows * j] - A[(size_t)j + (size_t)rows * i];
       asym += d * d; nrm += A[(size_t)i + (size_t)rows * j] * A[(size_t)i + (size_t)rows * j];
     }
-  if (std::sqrt(asym) > 1e-12 * std::sqrt(nrm))
-    throw Error(AOADMM_ERR_UNSUPPORTED, "quadratic regularization with a non-symmetric L is not in the device path");
+  const size_t nn = (size_t)rows * rows * sizeof(double);
+  if (std::sqrt(asym) > 1e-12 * std::sqrt(nrm)) {      // no orthogonal eigenbasis: inverse per value of rho (refresh)
+    nonsym = true;
+    g_cached = -1.0;
+    Lh = A;
+    L.alloc(nn); Minv.alloc(nn);
+    AO_HIP(hipMemcpyAsync(L.p, L_host, nn, hipMemcpyHostToDevice, s));
+    AO_HIP(hipStreamSynchronize(s));
+    return;
+  }
+  nonsym = false;
   const int sweeps = host_sym_eig(rows, A, wv, Uv);
   AO_REQUIRE(sweeps >= 0, "eigendecomposition of the quadratic-regularization matrix did not converge");
   std::vector<double> Utv((size_t)rows * rows);
   for (int64_t j = 0; j < rows; ++j)
     for (int64_t i = 0; i < rows; ++i) Utv[(size_t)j + (size_t)rows * i] = Uv[(size_t)i + (size_t)rows * j];
-  const size_t nn = (size_t)rows * rows * sizeof(double);
   L.alloc(nn); U.alloc(nn); Ut.alloc(nn); w.alloc((size_t)rows * sizeof(double));
   AO_HIP(hipMemcpyAsync(L.p, L_host, nn, hipMemcpyHostToDevice, s));
   AO_HIP(hipMemcpyAsync(U.p, Uv.data(), nn, hipMemcpyHostToDevice, s));
   AO_HIP(hipMemcpyAsync(Ut.p, Utv.data(), nn, hipMemcpyHostToDevice, s));
   AO_HIP(hipMemcpyAsync(w.p, wv.data(), (size_t)rows * sizeof(double), hipMemcpyHostToDevice, s));
   AO_HIP(hipStreamSynchronize(s));
+}
+
+const double* QuadPrep::refresh(double eta, const double* rho_dev, double rho_mul, hipStream_t s) {
+  AO_REQUIRE(nonsym && n > 0 && Minv.p, "quadratic regularization: non-symmetric matrix not prepared");
+  double rho = 0.0;
+  AO_HIP(hipMemcpyAsync(&rho, rho_dev, sizeof rho, hipMemcpyDeviceToHost, s));
+  AO_HIP(hipStreamSynchronize(s));
+  const double g = 2.0 * (eta / (rho * rho_mul));
+  if (g == g_cached) return Minv.d();
+  // in-place Gauss-Jordan inverse of M = g*L + I with row pivoting, row-major so that every row operation is contiguous
+  const int64_t N = n;
+  std::vector<double> a((size_t)N * N);
+  for (int64_t i = 0; i < N; ++i)
+    for (int64_t j = 0; j < N; ++j) a[(size_t)i * N + j] = g * Lh[(size_t)i + (size_t)N * j] + (i == j ? 1.0 : 0.0);
+  std::vector<int64_t> piv(N);
+  for (int64_t k = 0; k < N; ++k) {
+    int64_t p = k;
+    double best = std::fabs(a[(size_t)k * N + k]);
+    for (int64_t i = k + 1; i < N; ++i) {
+      const double v = std::fabs(a[(size_t)i * N + k]);
+      if (v > best) { best = v; p = i; }
+    }
+    if (!(best > 0.0) || !std::isfinite(best))
+      throw Error(AOADMM_ERR_INVALID, "quadratic regularization: 2*eta/rho*L + I is singular (MATLAB's \\ would return Inf/NaN)");
+    piv[k] = p;
+    double* rk = &a[(size_t)k * N];
+    if (p != k) {
+      double* rp = &a[(size_t)p * N];
+      for (int64_t j = 0; j < N; ++j) std::swap(rk[j], rp[j]);
+    }
+    const double inv = 1.0 / rk[k];
+    rk[k] = 1.0;
+    for (int64_t j = 0; j < N; ++j) rk[j] *= inv;
+    for (int64_t i = 0; i < N; ++i) {
+      if (i == k) continue;
+      double* ri = &a[(size_t)i * N];
+      const double f = ri[k];
+      if (f == 0.0) continue;
+      ri[k] = 0.0;
+      for (int64_t j = 0; j < N; ++j) ri[j] -= f * rk[j];
+    }
+  }
+  for (int64_t k = N - 1; k >= 0; --k)                 // undo the row exchanges as column exchanges, last first
+    if (piv[k] != k)
+      for (int64_t i = 0; i < N; ++i) std::swap(a[(size_t)i * N + k], a[(size_t)i * N + piv[k]]);
+  std::vector<double> cm((size_t)N * N);
+  for (int64_t i = 0; i < N; ++i)
+    for (int64_t j = 0; j < N; ++j) cm[(size_t)i + (size_t)N * j] = a[(size_t)i * N + j];
+  AO_HIP(hipMemcpyAsync(Minv.p, cm.data(), cm.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  AO_HIP(hipStreamSynchronize(s));                     // cm is a local
+  g_cached = g;
+  return Minv.d();
 }
 
 // W(i,:) *= 1 / (2*eta/rho*w_i + 1)
@@ -1266,6 +1326,11 @@ void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, 
       break;
     case AOADMM_C_ORTHONORMAL: prox_ortho(V, ldv, Zout, ldz, rows, R, ws, ctl, s); break;
     case AOADMM_C_QUADRATIC: {                       // (2*eta/rho*L + I) \ x = U diag(1/(2 eta/rho w + 1)) U' x   (:66)
+      if (ps.quad) {                                 // non-symmetric L: Z = (2*eta/rho*L + I)^-1 * V, inverse cached per rho
+        const double* Mi = ps.quad->refresh(ps.p0, rho_dev, rho_mul, s);
+        gemm_small(Zout, ldz, Mi, rows, V, ldv, rows, (int)rows, R, 0, coef(1.0), 0.0, ctl, s);
+        break;
+      }
       AO_REQUIRE(ps.LU && ps.LUt && ps.Lw, "quadratic regularization: matrix not prepared");
       gemm_small(ws, rows, ps.LUt, rows, V, ldv, rows, (int)rows, R, 0, coef(1.0), 0.0, ctl, s);
       int64_t nb = cdiv(rows * R, 256);

@@ -67,6 +67,31 @@ def test_cp_tv_long_mode(pkg, eng):
     compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=6)))
 
 
+def test_cp_quadratic_nonsymmetric(pkg, eng):
+    """{'quadratic regularization', eta, L} with a NON-symmetric L (constraints_to_prox.m:62-67 solves
+    (2 eta/rho L + I) \\ x for any L): no eigenbasis, the library inverts the matrix on the host whenever rho has moved
+    and the device prox is one GEMM.  Solver parity at 1e-8, op-level at 1e-11, and a symmetric L right after it on the
+    same engine (the two preparations must not leak into each other)."""
+    rng = np.random.default_rng(52)
+    n = 41
+    L = np.triu(rng.random((n, n)), 1) * 0.6 + np.diag(1.0 + rng.random(n)) - 0.2 * np.tril(rng.random((n, n)), -1)
+    assert np.linalg.norm(L - L.T) > 0.1 * np.linalg.norm(L)
+    Z, io, _ = cp_model((n, 18, 15), 3, rng, [('quadratic regularization', 0.05, L), ('non-negativity',), None])
+    compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=10)))
+    x = rng.standard_normal((n, 5))
+    for rho in (0.7, 0.7, 2.5):                          # same rho twice: the cached inverse is reused
+        got = eng.prox(('quadratic regularization', 0.05, L), x, rho)
+        ref = np.linalg.solve(2.0 * 0.05 / rho * L + np.eye(n), x)
+        assert rel_fro(got, ref) < 1e-11
+    Ls = L + L.T
+    got = eng.prox(('quadratic regularization', 0.05, Ls), x, 0.7)
+    assert rel_fro(got, np.linalg.solve(2.0 * 0.05 / 0.7 * Ls + np.eye(n), x)) < 1e-11
+    # a coupled/permuted matrix that needs row exchanges: zero diagonal after scaling
+    P = np.roll(np.eye(n), 1, axis=0) * 50.0 - np.eye(n) * (0.7 / (2.0 * 0.05))     # 2 eta/rho L + I has a zero diagonal
+    got = eng.prox(('quadratic regularization', 0.05, P), x, 0.7)
+    assert rel_fro(got, np.linalg.solve(2.0 * 0.05 / 0.7 * P + np.eye(n), x)) < 1e-11
+
+
 def test_cp_mixed_constraints_and_ls(pkg, eng):
     rng = np.random.default_rng(3)
     Z, io, _ = cp_model((30, 25, 20), 4, rng, [None, ('l2-ball', 1.0), ('unimodality', True)])
