@@ -103,7 +103,8 @@ struct WgLoopU {
   const double* Binv;       // inv(L*L'), R x R (shared system; unused with per_row)
   const double* L;          // with per_row: the rows' Cholesky factors, [rows][R*R]
   const double* rho;        // device scalar, or one value per row with per_row
-  const double* rho_prox;   // device scalar the prox sees (max(rho) for a PARAFAC2 C mode, :1423-1424)
+  const double* rho_prox;   // device scalar the prox sees (max(rho) for a PARAFAC2 C mode, :1423-1424); null with
+                            // per_row: the kernel takes the maximum of the rows' rho itself
   double *fac, *Z, *mu;     // rows x R each
   int64_t rows;
   int R;

@@ -1469,7 +1469,21 @@ __global__ __launch_bounds__(NT) void admm_loop_wg_k(WgLoopU a) {
     }
   }
   const double rho = SOLVE == 2 ? a.rho[i] : a.rho[0];
-  const double rho_prox = a.rho_prox[0];             // max(rho) of a PARAFAC2 C mode (:1423-1424); rho otherwise
+  double rho_prox;                                   // max(rho) of a PARAFAC2 C mode (:1423-1424); rho otherwise
+  if (SOLVE == 2 && a.rho_prox == nullptr) {         // the rows' own rho are this block's registers: max without a launch
+    double mx = rho;                                 // padding threads hold the last row's value
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if ((t & 63) == 0) red[t >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int q = 1; q < NW; ++q) mx = fmax(mx, red[q]);
+    rho_prox = mx;
+    __syncthreads();                                 // red is reused by the loop
+  } else {
+    rho_prox = a.rho_prox[0];
+  }
   const double rh = rho / 2;
   const ElemProx ep = elem_prox_of(a.ptype, a.p0, a.p1, rho_prox);
   const bool colnorm = a.ptype == AOADMM_C_L2_BALL || a.ptype == AOADMM_C_NONNEG_L2_BALL ||

@@ -1876,6 +1876,8 @@ struct WgLoopArgs {
   const double* LAA;
   double tol_pr_coupl, tol_pr_constr, tol_du_coupl, tol_du_constr;
   AdmmCtl* ctl;
+  int self_start = 0;       // registers kernel: opens the loop itself and takes rho_j / sum rho from the modes' rho
+                            // (no ctl_reset / coupling_coefs_k launch in front of it)
 };
 template <int RMAX>
 __global__ __launch_bounds__(256) void couple_loop_wg_k(WgLoopArgs a) {
@@ -2172,7 +2174,7 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
     const WgLoopMode& m = a.m[j];
     rho[j] = m.rho[0];
     rh[j] = rho[j] / 2;
-    cj[j] = T4 ? 0.0 : a.coefs[j];                    // rho_j / sum rho
+    cj[j] = (T4 || a.self_start) ? 0.0 : a.coefs[j];  // rho_j / sum rho
     ep[j] = elem_prox_of(m.ptype, m.p0, m.p1, rho[j]);
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
@@ -2186,10 +2188,17 @@ __global__ __launch_bounds__(256) void couple_loop_wg_regs_k(WgLoopArgs a) {
       zo[j][r] = z[j][r];
     }
   }
+  if (!T4 && a.self_start) {                          // coupling_coefs_k's arithmetic: 1 / sum(rho) * rho_j, modes in order
+    double srho = 0.0;
+#pragma unroll
+    for (int j = 0; j < NM; ++j) srho += rho[j];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) cj[j] = 1.0 / srho * rho[j];
+  }
   double dold[RMAX], dd[RMAX];
 #pragma unroll
   for (int c = 0; c < RMAX; ++c) { dold[c] = d[c]; dd[c] = 0.0; }
-  if (t == 0) go = a.ctl->active;
+  if (t == 0) go = a.self_start ? 1 : a.ctl->active;
   __syncthreads();
   int it = 0;
   bool ran = false;
@@ -2414,8 +2423,22 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
     const size_t nimg = (size_t)std::max(mi.rows * mi.R, mi.img_rows * mi.img_cols) * sizeof(double);
     mi.TD.ensure(nimg); mi.TF.ensure(nimg); mi.tmp.ensure(nimg); mi.W1.ensure(nimg); mi.W2.ensure(nimg);
   }
+  // the one-launch registers loop (couple_loop_wg_regs_k) opens the loop and forms rho_j / sum rho itself
+  bool regs_path = false;
+  {
+    static const bool off = getenv("AOADMM_GENERIC_COUPLING") != nullptr, no_wg = getenv("AOADMM_NO_WG_LOOP") != nullptr;
+    int rmax = (int)ci.cols;
+    bool local_prox = true, pc = false;
+    for (int j = 0; j < n; ++j) {
+      const ModeInfo& mi = modes_[ci.modes[j]];
+      rmax = std::max(rmax, mi.R);
+      local_prox = local_prox && (!mi.constrained || prox_is_fusable(mi.prox.type));
+      pc = pc || (tensors_[mi.tensor].par2 && mi.pos == 2);
+    }
+    regs_path = (ty == 0 || ty == 4) && !pc && !off && !no_wg && local_prox && n <= 3 && ci.rows <= 256 && rmax <= 8;
+  }
   // reset the loop control (the per-mode sys_build calls reset their own blocks); types 0-2: in coupling_coefs_k below
-  if (!(ty == 0 || ty == 1 || ty == 2)) ctl_reset(ctl, stream_);
+  if (!(ty == 0 || ty == 1 || ty == 2) && !regs_path) ctl_reset(ctl, stream_);
   // per-outer-iteration constants
   std::vector<const double*> hp(n);
   bool any_pc = false;                                // a PARAFAC2 C mode in this coupling (types 0 and 1 only)
@@ -2437,8 +2460,10 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
   }
   const double* rho_last = modes_[ci.modes[n - 1]].rho.d();   // type 5: rhoC = mean(rho{mm}) with the stale loop variable (:1032)
   if (ty == 0 || ty == 1 || ty == 2) {
-    coupling_coefs_k<<<1, 64, 0, stream_>>>(ci.coef.d(), rho_ptrs.as<const double*>(), n, ctl);
-    AO_KERNEL_CHECK();
+    if (!regs_path) {
+      coupling_coefs_k<<<1, 64, 0, stream_>>>(ci.coef.d(), rho_ptrs.as<const double*>(), n, ctl);
+      AO_KERNEL_CHECK();
+    }
   } else if (ty == 4 || ty == 5) {
     AAArgs aa, aaa;                                   // aaa: the PARAFAC2 C mode's H*H' kept apart (:946-948)
     aa.n = 0; aa.Rc = (int)ci.cols; aaa.n = 0; aaa.Rc = (int)ci.cols;
@@ -2510,7 +2535,9 @@ void Engine::coupled_admm(int c, const aoadmm_options& opt) {
           wm.R = mi.R; wm.constrained = mi.constrained ? 1 : 0; wm.ptype = mi.prox.type; wm.p0 = mi.prox.p0; wm.p1 = mi.prox.p1;
           lds += (size_t)mi.R * mi.R + (size_t)q * mi.R;
         }
+        AO_REQUIRE(regs_path == (rows <= 256 && rmax <= 8 && n <= 3), "coupled loop: path prediction and launch disagree");
         if (rows <= 256 && rmax <= 8 && n <= 3) {     // one row per thread: the state stays in registers
+          wa.self_start = 1;
 #define AO_WGR(RM, NMM) { if (ty == 4) couple_loop_wg_regs_k<RM, NMM, true><<<1, 256, 0, stream_>>>(wa); \
                           else couple_loop_wg_regs_k<RM, NMM, false><<<1, 256, 0, stream_>>>(wa); }
           if (rmax <= 4) { if (n == 1) AO_WGR(4, 1) else if (n == 2) AO_WGR(4, 2) else AO_WGR(4, 3) }

@@ -225,13 +225,14 @@ void Engine::par2_update_C(int m, const aoadmm_options& opt) {
     allreduce(b.rhoc.d(), b.K);
     allreduce(b.Lc.d(), (int64_t)b.K * RR);
   }
-  par2_rho_max(b.rhoc.d(), b.K, b.rhomax.d(), stream_);
+  const bool wg_loop = mi.constrained && admm_loop_wg_ok(mi.rows, mi.R, mi.prox.type, opt.MaxInnerIters);
+  if (!wg_loop) par2_rho_max(b.rhoc.d(), b.K, b.rhomax.d(), stream_);   // the one-workgroup loop takes max(rho) itself
   const P2Dims dall = b.dims_all();                   // the K x R row systems are solved on every rank
   t.last_pos = 2;                                                                        // last_m(p) = 3
-  if (mi.constrained && admm_loop_wg_ok(mi.rows, mi.R, mi.prox.type, opt.MaxInnerIters)) {
+  if (wg_loop) {
     // K <= 256 rows: the K row systems, update_constraint with max(rho) and the loop test in one launch (:602-606)
     WgLoopU wa;
-    wa.A = b.ac.d(); wa.Binv = nullptr; wa.L = b.Lc.d(); wa.rho = b.rhoc.d(); wa.rho_prox = b.rhomax.d();
+    wa.A = b.ac.d(); wa.Binv = nullptr; wa.L = b.Lc.d(); wa.rho = b.rhoc.d(); wa.rho_prox = nullptr;
     wa.fac = mi.fac.d(); wa.Z = mi.Z.d(); wa.mu = mi.mu.d();
     wa.rows = mi.rows; wa.R = mi.R; wa.per_row = 1;
     wa.ptype = mi.prox.type; wa.p0 = mi.prox.p0; wa.p1 = mi.prox.p1;
