@@ -47,9 +47,10 @@ struct QuadPrep {
 size_t iso_ws_bytes(int64_t rows, int R);
 void prox_iso(const double* V, int64_t ldv, double* Z, int64_t ldz, int64_t rows, int R, int mode, double nonneg,
               double* ws, const AdmmCtl* ctl, hipStream_t s);
-// false: the column is too long for the LDS-resident cyclic reduction (the caller solves sequentially)
+// beyond 4096 rows the reduction runs in `ws` (prox_gl_ws_doubles); false: no workspace (the caller solves sequentially)
 bool prox_gl_pcr(const double* V, int64_t ldv, double* Z, int64_t ldz, int64_t rows, int R, double eta, const double* rho,
-                 double rho_mul, const AdmmCtl* ctl, hipStream_t s);
+                 double rho_mul, const AdmmCtl* ctl, hipStream_t s, double* ws = nullptr);
+size_t prox_gl_ws_doubles(int64_t rows, int R);
 
 bool prox_is_fusable(int type);
 // constraints with a reg_func entry (constraints_to_prox.m): their value enters f_tensors (cmtf_fun_AOADMM.m:1272-1288)

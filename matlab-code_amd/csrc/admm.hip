@@ -1259,7 +1259,7 @@ size_t prox_ws_bytes(int type, int64_t rows, int R) {
     case AOADMM_C_NONDECREASING:
     case AOADMM_C_NONINCREASING:
     case AOADMM_C_UNIMODAL: return iso_ws_bytes(rows, R);
-    case AOADMM_C_GL_SMOOTH: return (size_t)R * rows * sizeof(double);
+    case AOADMM_C_GL_SMOOTH: return prox_gl_ws_doubles(rows, R) * sizeof(double);
     case AOADMM_C_ORTHONORMAL: return ortho_ws_doubles(rows, R) * sizeof(double);
     case AOADMM_C_QUADRATIC: return (size_t)R * rows * sizeof(double);
     case AOADMM_C_TV: return rows > kTvParMax ? (size_t)R * tv_ws_doubles(rows) * sizeof(double) : 16;
@@ -1322,7 +1322,7 @@ void prox_apply(const ProxSpec& ps, const double* V, int64_t ldv, double* Zout, 
     case AOADMM_C_NONINCREASING: prox_iso(V, ldv, Zout, ldz, rows, R, 1, 0.0, ws, ctl, s); break;
     case AOADMM_C_UNIMODAL: prox_iso(V, ldv, Zout, ldz, rows, R, 2, ps.p0, ws, ctl, s); break;
     case AOADMM_C_GL_SMOOTH:
-      if (!prox_gl_pcr(V, ldv, Zout, ldz, rows, R, ps.p0, rho_dev, rho_mul, ctl, s)) prox_gl_k<<<R, 64, 0, s>>>(a, ctl);
+      if (!prox_gl_pcr(V, ldv, Zout, ldz, rows, R, ps.p0, rho_dev, rho_mul, ctl, s, ws)) prox_gl_k<<<R, 64, 0, s>>>(a, ctl);
       break;
     case AOADMM_C_ORTHONORMAL: prox_ortho(V, ldv, Zout, ldz, rows, R, ws, ctl, s); break;
     case AOADMM_C_QUADRATIC: {                       // (2*eta/rho*L + I) \ x = U diag(1/(2 eta/rho w + 1)) U' x   (:66)

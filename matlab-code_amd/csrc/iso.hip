@@ -435,11 +435,68 @@ __global__ __launch_bounds__(NTH) void prox_gl_pcr_k(IsoCol a, double eta, const
   }
 }
 
+// The same reduction for columns beyond the LDS-resident 4096 rows: the four coefficient arrays ping-pong between two
+// copies in the prox workspace (8 doubles per row and column, L2-resident), one barrier per round; the arithmetic
+// of an equation is that of prox_gl_pcr_k, statement for statement, so the result does not depend on the path.
+template <int NTH>
+__global__ __launch_bounds__(NTH) void prox_gl_pcr_long_k(IsoCol a, double eta, const double* rho, double rho_mul,
+                                                          const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  const int n = (int)a.rows;
+  const int r = blockIdx.x, t = threadIdx.x;
+  double* w = a.ws + (size_t)r * 8 * n;
+  const double* v = a.V + a.ldv * r;
+  double* z = a.Z + a.ldz * r;
+  const double s2 = 2.0 * (eta / (rho[0] * rho_mul));
+  for (int i = t; i < n; i += NTH) {
+    const double deg = (n == 1) ? 1.0 : ((i == 0 || i == n - 1) ? 1.0 : 2.0);
+    w[i] = i > 0 ? -s2 : 0.0;
+    w[n + i] = s2 * deg + 1.0;
+    w[2 * n + i] = i < n - 1 ? -s2 : 0.0;
+    w[3 * n + i] = v[i];
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int k = 1; k < n; k <<= 1) {
+    const double* A = w + (size_t)cur * 4 * n;
+    const double* B = A + n;
+    const double* Cc = B + n;
+    const double* D = Cc + n;
+    double* X = w + (size_t)(cur ^ 1) * 4 * n;
+    for (int i = t; i < n; i += NTH) {
+      const int lo = i - k, hi = i + k;
+      const double ra = A[i], rc = Cc[i];
+      double nb = B[i], nd = D[i], na = 0.0, nc = 0.0;
+      if (lo >= 0) {
+        const double al = -ra / B[lo];
+        nb += al * Cc[lo]; nd += al * D[lo]; na = al * A[lo];
+      }
+      if (hi < n) {
+        const double ga = -rc / B[hi];
+        nb += ga * A[hi]; nd += ga * D[hi]; nc = ga * Cc[hi];
+      }
+      X[i] = na; X[n + i] = nb; X[2 * n + i] = nc; X[3 * n + i] = nd;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const double* B = w + (size_t)cur * 4 * n + n;
+  const double* D = B + 2 * (size_t)n;
+  for (int i = t; i < n; i += NTH) z[i] = D[i] / B[i];
+}
+
+size_t prox_gl_ws_doubles(int64_t rows, int R) { return rows > 4096 ? (size_t)8 * rows * R : (size_t)rows * R; }
+
 bool prox_gl_pcr(const double* V, int64_t ldv, double* Z, int64_t ldz, int64_t rows, int R, double eta, const double* rho,
-                 double rho_mul, const AdmmCtl* ctl, hipStream_t s) {
-  if (rows > 4096) return false;                     // the caller falls back to the sequential Thomas solve
+                 double rho_mul, const AdmmCtl* ctl, hipStream_t s, double* ws) {
   IsoCol a;
-  a.V = V; a.Z = Z; a.ldv = ldv; a.ldz = ldz; a.rows = rows; a.R = R; a.nonneg = 0; a.ws = nullptr;
+  a.V = V; a.Z = Z; a.ldv = ldv; a.ldz = ldz; a.rows = rows; a.R = R; a.nonneg = 0; a.ws = ws;
+  if (rows > 4096) {
+    if (ws == nullptr || rows >= (int64_t(1) << 28)) return false;   // no workspace: the caller solves sequentially
+    prox_gl_pcr_long_k<1024><<<R, 1024, 0, s>>>(a, eta, rho, rho_mul, ctl);
+    AO_KERNEL_CHECK();
+    return true;
+  }
   const size_t sh = (size_t)4 * rows * sizeof(double);
   if (rows <= 256) {
     prox_gl_pcr_k<256, 1><<<R, 256, sh, s>>>(a, eta, rho, rho_mul, ctl);

@@ -101,6 +101,37 @@ def test_tv_prox_long_columns(eng, kind, rows):
     assert rel_fro(got, ref) < 1e-10 or np.max(np.abs(got - ref)) < 1e-12, rel_fro(got, ref)
 
 
+def _gl_banded(X, eta, rho):
+    """(2*eta/rho*L + I) \\ X with the path-graph Laplacian L (constraints_to_prox.m:68-76) by a banded solve: the
+    oracle builds the dense matrix (3 GB at 20 000 rows), so the long columns are checked against this and this
+    against the oracle at 4097 rows."""
+    from scipy.linalg import solve_banded
+    n = X.shape[0]
+    s2 = 2.0 * eta / rho
+    ab = np.zeros((3, n))
+    ab[0, 1:] = -s2
+    ab[2, :-1] = -s2
+    ab[1, :] = 2.0 * s2 + 1.0
+    ab[1, 0] = ab[1, -1] = s2 + 1.0
+    return solve_banded((1, 1), ab, X)
+
+
+@pytest.mark.parametrize('rows', [4097, 9000, 20011])
+@pytest.mark.parametrize('eta', [0.7, 40.0, 1e-3])
+def test_gl_prox_long_columns(eng, rows, eta):
+    """GL smoothness beyond the LDS-resident 4096 rows: the same cyclic reduction with its coefficient arrays in the
+    prox workspace (prox_gl_pcr_long_k) instead of the one-thread Thomas solve."""
+    rng = np.random.default_rng(rows)
+    X = np.cumsum(rng.standard_normal((rows, 3)), axis=0) * 0.05 + rng.standard_normal((rows, 3))
+    c = ('GL smoothness', eta)
+    ref = _gl_banded(X, eta, 1.7)
+    if rows == 4097:
+        ops, _ = OP.constraints_to_prox([1], [c], [rows])
+        assert rel_fro(ref, ops[0](X, 1.7)) < 1e-12
+    got = eng.prox(c, X, 1.7)
+    assert rel_fro(got, ref) < 1e-10, rel_fro(got, ref)
+
+
 SHAPE_CASES = [('non-decreasing',), ('non-increasing',), ('unimodality', True), ('unimodality', False), ('GL smoothness', 0.7)]
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development timing of the TV prox on columns beyond the LDS-resident 4096 rows (run under rocprofv3 --kernel-trace
+"""Development timing of the TV and GL-smoothness prox on columns beyond the LDS-resident 4096 rows (run under rocprofv3 --kernel-trace
 --stats; with AOADMM_TV_SEQ_LONG=1 the one-thread scan it replaced)."""
 import importlib, os, sys
 import numpy as np
@@ -13,4 +13,6 @@ for rows in (2000, 4096, 6000, 8000, 20000, 100000):
     X = steps + 0.05 * rng.standard_normal((rows, 20))
     for _ in range(5):
         eng.prox(('TV regularization', 0.3), X, 1.7)
+    for _ in range(5):
+        eng.prox(('GL smoothness', 0.7), X, 1.7)
 eng.close()
