@@ -11,6 +11,10 @@ timeout -k 10 900 python -m pytest tests -m gpu -x -q > $OUT/gputests.log 2>&1; 
 tail -2 $OUT/gputests.log
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $OUT/r02_bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --prec f64 --no-cpu-baseline > $OUT/r02_bench_f64.json 2> $OUT/bench_f64.err; echo "bench f64 rc=$?"
+# the driver's launch shape for one rank, and the N > 1 data path (own-rows buffer + ncclAllReduce of every MTTKRP output)
+# on a one-rank RCCL communicator: the only forms of the multi-GPU path a one-GPU box can run at full size
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline --no-drift > $OUT/r02_bench_torchrun_n1.json 2> $OUT/torchrun.err; echo "torchrun n1 rc=$?"
+AOADMM_BENCH_ONE_RANK_COMM=1 timeout -k 10 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-drift > $OUT/r02_bench_one_rank_comm.json 2> $OUT/onerank.err; echo "one-rank comm rc=$?"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-drift > $OUT/r02_bench_under_rocprof.json 2> $OUT/prof.err; echo "prof rc=$?"
 find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/r02_kernel_stats.csv
