@@ -2993,7 +2993,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
         Par2Block& b = t.p2;
         const double* res = hp2v[p];
         const double* q = res + b.K + 1;
-        if (res[b.K] > 0)                           // some rank's slabs hit a non-positive-definite system
+        if (b.slab_sharded && res[b.K] > 0)         // some rank's slabs hit a non-positive-definite system (the slot is only written then)
           throw Error(AOADMM_ERR_NOT_PD, "Cholesky failed in a PARAFAC2 slab system on another rank (chol in cmtf_fun_AOADMM.m:212/240)");
         double fp = 0.0;
         if (masked) fp = hem[4 * p + 2];                                                        // :1249-1252
