@@ -100,6 +100,11 @@ def parse_args(argv=None):
     ap.add_argument('--prec', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-rows', type=int, default=0, help='mode-1 rows of the CPU baseline sample (0: sized by a probe)')
+    ap.add_argument('--as-rank', type=int, default=-1,
+                    help="with --of N: time rank R's share of an N-GPU job on ONE GPU (its row block of mode 1, its mode-3 slab "
+                         'of the mode-1 pass, own-rows buffers, every collective issued on a one-rank RCCL communicator); '
+                         'a measurement of the per-rank step, not a solve of the problem')
+    ap.add_argument('--of', type=int, default=0)
     ap.add_argument('--no-drift', action='store_true',
                     help='skip the fp64 repeat of the same iterations (N = 1, fp32 runs only) that measures the factor drift')
     return ap.parse_args(argv)
@@ -180,6 +185,10 @@ def main():
     eng = pkg.Engine(local_rank)
     if world > 1:
         pkg.init_engine_comm(eng, dist)               # data plane: RCCL inside the library
+    elif args.as_rank >= 0:
+        if not (args.of > 1 and args.as_rank < args.of):
+            raise SystemExit('bench.py: --as-rank R needs --of N with 0 <= R < N, N > 1')
+        eng.comm_init_rank_share(eng.comm_unique_id(), args.as_rank, args.of)
     elif os.environ.get('AOADMM_BENCH_ONE_RANK_COMM'):
         # development switch: run the N > 1 data path (zero-filled own-rows buffer + ncclAllReduce of every MTTKRP
         # output) with a one-rank RCCL communicator -- the only form a one-GPU box can exercise at full size
@@ -233,7 +242,8 @@ def main():
     # factors after exactly warmup + steps iterations, for the fp32-vs-fp64 comparison below (the runs that follow
     # iterate further)
     fac32 = None
-    if world == 1 and args.prec == 'f32' and not args.no_drift:
+    share = args.of if args.as_rank >= 0 else 1            # > 1: this process did 1/share of the job (--as-rank)
+    if world == 1 and share == 1 and args.prec == 'f32' and not args.no_drift:
         fac32 = pkg.download_state(eng, Z, G0)['fac']
 
     # where the time outside the tensor passes goes: a few more iterations with the reductions over T timed as well
@@ -283,6 +293,7 @@ def main():
     # same iterations: relative Frobenius gap of the factors.  Outside the timed region; the engines run one after the
     # other (96 GB, then 192 GB of HBM at 2000^3).
     drift = None
+    parity_mode = None
     if fac32 is not None:
         try:
             eng.close()
@@ -293,11 +304,32 @@ def main():
             pkg.upload_state(eng, Z64, copy.deepcopy(G0))
             if args.warmup > 0:
                 pkg.run_solver(eng, opts(args.warmup), 3)
+            capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 0, 1, None, None, None, None))
             eng.synchronize()
             t1 = time.perf_counter()
             pkg.run_solver(eng, opts(args.steps), 3)
             eng.synchronize()
             dt64 = time.perf_counter() - t1
+            ms64 = C.c_double(); nl64 = C.c_int64(); by64 = C.c_double()
+            capi.check(eng.lib.aoadmm_kernel_stats(eng.h, 0, 1, C.byref(ms64), C.byref(nl64), C.byref(by64), None))
+            if nl64.value > 0 and ms64.value > 0:
+                a64 = ms64.value / nl64.value
+                ach64 = by64.value / nl64.value / (a64 * 1e-3) / 1e9
+                tr64 = None
+                import glob as _glob
+                c64 = sorted(_glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_contract_f64.json')))
+                if c64 and args.size == 2000 and R == 20:
+                    try:
+                        tr64 = float(json.load(open(c64[-1]))['hbm_traffic_bytes_per_launch'])
+                    except Exception:
+                        tr64 = None
+                parity_mode = {
+                    'what': 'the same workload with the tensor stored and contracted in IEEE double (the reference is double '
+                            'throughout): the mode that is compared with the oracle at 1e-8',
+                    'iters_s': args.steps / dt64, 'ms_per_step': dt64 / args.steps * 1e3, 'dtype': 'f64',
+                    'roofline': {'bound': 'hbm', 'kernel': 'contract_f64', 'avg_launch_ms': a64, 'launches': int(nl64.value),
+                                 'algorithmic_bytes_per_launch': by64.value / nl64.value, 'achieved': ach64,
+                                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach64 / HBM_PEAK_GBS, 'traffic': tr64}}
             fac64 = pkg.download_state(eng, Z64, G0)['fac']
             drift = {'factor_rel_fro_f32_vs_f64': [float(np.linalg.norm(a - b) / np.linalg.norm(b)) for a, b in zip(fac32, fac64)],
                      'outer_iterations': args.warmup + args.steps, 'f64_ms_per_step': dt64 / args.steps * 1e3,
@@ -311,7 +343,7 @@ def main():
         avg_ms = ms.value / launches
         bytes_per_launch = by.value / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        flops_mttkrp = 2.0 * I * J * K * R
+        flops_mttkrp = 2.0 * I * J * K * R / share
         # HBM bytes per launch from the PMC pass committed under profiles/ (separate rocprofv3 --pmc runs,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); only valid for this exact workload
         traffic = None
@@ -319,7 +351,7 @@ def main():
         kname = 'contract16_f32' if args.prec == 'f32' else 'contract_f64'
         cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_%s.json' % kname)))   # newest round last
         pmc = cands[-1] if cands else ''
-        if world == 1 and args.size == 2000 and R == 20 and pmc:
+        if world == 1 and share == 1 and args.size == 2000 and R == 20 and pmc:
             try:
                 traffic = float(json.load(open(pmc))['hbm_traffic_bytes_per_launch'])
             except Exception:
@@ -334,7 +366,10 @@ def main():
             'scaling': 'strong', 'vs_baseline': None, 'dtype': args.prec, 'data': 'synthetic',
             'config': {'workload': 'cfg5: %dx%dx%d R=%d CP, mode1 TV(0.001), modes2-3 nonneg, %s tensor + fp64 solve, '
                                    'MaxInnerIters=5, tol=0' % (I, J, K, R, args.prec),
-                       'sharding': 'mode-1 rows over %d GPU(s), factors replicated' % world,
+                       'sharding': ('mode-1 rows over %d GPU(s), factors replicated' % world) if share == 1 else
+                                   ('rank %d of %d on ONE GPU (--as-rank): this rank\'s mode-1 row block and mode-3 slab, every '
+                                    'collective issued on a one-rank RCCL communicator; a per-rank timing, not a solve'
+                                    % (args.as_rank, args.of)),
                        'tensor_passes_per_iter': round((launches + int(nl1.value)) / args.steps, 2),
                        'resident_copies': 'X(i,j,k) + mode-permuted X(j,k,i) and X(k,i,j): 3 x %.0f GB per node, '
                                           'every pass contracts a trailing mode'
@@ -343,7 +378,9 @@ def main():
             'mttkrp_mode1_ms': mttkrp_ms,
             'mttkrp_mfma_frac_f32_peak': flops_mttkrp / (mttkrp_ms * 1e-3) / 1e12 / (F32_MFMA_PEAK_TF * world),
             'f_tensors_last': out['f_tensors'],
+            'rank_share': None if share == 1 else {'rank': args.as_rank, 'of': args.of},
             'fp32_drift': drift,
+            'parity_mode': parity_mode,
             'collectives': {'backend': 'rccl' if world > 1 else 'none', 'ranks': comm['comm_ranks'],
                             'rccl_version': comm['rccl_version'], 'librccl': comm['librccl']},
             'datagen_s': t_gen,
@@ -361,7 +398,7 @@ def main():
                               'avg_launch_ms': (ms1.value / nl1.value) if nl1.value else None,
                               'achieved_GBps': (by1.value / nl1.value / (ms1.value / nl1.value * 1e-3) / 1e9) if nl1.value and ms1.value > 0 else None},
         }
-        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and share == 1:      # reported on rank 0 at N = 1 only
             try:
                 line['cpu_baseline'] = cpu_baseline(I, J, K, R, rows=(min(args.cpu_rows, I) if args.cpu_rows > 0 else None))
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number

@@ -167,6 +167,11 @@ int aoadmm_set_progress(aoadmm_ctx* ctx, aoadmm_progress_fn fn, void* user, int 
  * are replicated and only MTTKRP partials cross xGMI. */
 int aoadmm_comm_unique_id(char id[128]);
 int aoadmm_comm_init_rank(aoadmm_ctx* ctx, const char id[128], int rank, int world);
+/* Measurement hook (bench.py --as-rank R --of N): the context takes rank `rank` of `world` in every sharding decision
+ * (row block of mode 1, mode-3 slab of the mode-1 pass, own-rows buffers) but joins a ONE-rank RCCL communicator, so
+ * every collective is issued (ncclAllReduce on the library's stream) without peers.  It times one rank's share of an
+ * N-GPU job on a one-GPU box; the sums are that rank's partial sums only, so the factors are NOT those of the N-rank job. */
+int aoadmm_comm_init_rank_share(aoadmm_ctx* ctx, const char id[128], int rank, int world);
 /* Bring-up/test transport: `world` contexts driven by threads of ONE process (on one device or several) form
  * group `key`; collectives go through host staging in rank order.  It lets the sharded data path run with
  * world > 1 on a single GPU, which RCCL refuses.  Every rank must make the same sequence of library calls. */

@@ -24,7 +24,7 @@ PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_
 # every symbol include/aoadmm_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     'aoadmm_abi_version', 'aoadmm_last_error', 'aoadmm_device_count', 'aoadmm_create', 'aoadmm_create_multi', 'aoadmm_destroy',
-    'aoadmm_synchronize', 'aoadmm_set_progress', 'aoadmm_comm_unique_id', 'aoadmm_comm_init_rank', 'aoadmm_comm_init_local', 'aoadmm_comm_rank', 'aoadmm_comm_info',
+    'aoadmm_synchronize', 'aoadmm_set_progress', 'aoadmm_comm_unique_id', 'aoadmm_comm_init_rank', 'aoadmm_comm_init_rank_share', 'aoadmm_comm_init_local', 'aoadmm_comm_rank', 'aoadmm_comm_info',
     'aoadmm_model_begin', 'aoadmm_model_set_mode', 'aoadmm_model_set_mode_slabs', 'aoadmm_model_add_cp',
     'aoadmm_model_add_par2', 'aoadmm_model_set_constraint', 'aoadmm_model_set_coupling',
     'aoadmm_model_set_coupling_type', 'aoadmm_model_set_ridge', 'aoadmm_model_end', 'aoadmm_tensor_upload',
@@ -98,6 +98,7 @@ def load_library():
     lib.aoadmm_set_progress.argtypes = [vp, PROGRESS_FN, vp, C.c_int]
     lib.aoadmm_comm_unique_id.argtypes = [C.c_char_p]
     lib.aoadmm_comm_init_rank.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    lib.aoadmm_comm_init_rank_share.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     lib.aoadmm_comm_init_local.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.aoadmm_comm_rank.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.aoadmm_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]

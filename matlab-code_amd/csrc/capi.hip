@@ -32,6 +32,7 @@ struct MultiCtx {
   uint64_t gen = 0;
   int pending = 0;
   bool quit = false;
+  bool poisoned = false;                  // set when run() had to abort communicators; never cleared
   std::vector<int> code;
   std::vector<std::string> msg;
   std::vector<char> done;
@@ -85,6 +86,9 @@ struct MultiCtx {
   void run(const std::function<void(Engine&, int)>& f) {
     {
       std::unique_lock<std::mutex> lk(m);
+      // sticky: once a peer's communicator had to be aborted the ranks are out of step for good (the aborted ones would
+      // skip collectives the failed one still enters), so every later call fails at once instead of computing on
+      if (poisoned) throw Error(AOADMM_ERR_RCCL, "multi-device context unusable: a rank failed alone and its peers' communicators were aborted; destroy the context");
       job = f;
       pending = (int)eng.size();
       done.assign(eng.size(), 0);
@@ -107,6 +111,7 @@ struct MultiCtx {
             for (size_t r = 0; r < eng.size(); ++r)
               if (!done[r]) eng[r]->comm_abort();
             aborted = true;
+            poisoned = true;
           }
         }
         while (!rows.empty()) {
@@ -286,6 +291,14 @@ int aoadmm_comm_init_rank(aoadmm_ctx* ctx, const char id[128], int rank, int wor
   return guarded([&] {
     AO_REQUIRE(!ctx->multi, "a multi-device context owns its communicator");
     ctx->eng->comm_init(id, rank, world);
+  });
+}
+int aoadmm_comm_init_rank_share(aoadmm_ctx* ctx, const char id[128], int rank, int world) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(!ctx->multi, "a multi-device context owns its communicator");
+    AO_REQUIRE(id != nullptr, "aoadmm_comm_init_rank_share needs the id from aoadmm_comm_unique_id");
+    ctx->eng->comm_init(id, rank, world, true);
   });
 }
 int aoadmm_comm_init_local(aoadmm_ctx* ctx, int key, int rank, int world) {

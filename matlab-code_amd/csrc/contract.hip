@@ -45,6 +45,8 @@ struct KArgs {
   void* T;             // float (f32 tensors) or double (f64 tensors), [nchunk][trows][R]
   int64_t tiles_per_batch, ntiles, batch_stride, M, ld, C, Cg, trows;
   int groups_per_chunk, R;
+  int flush_every;     // contract16_f32<1, *, true>: steady-state loop rounds (24 columns each) between two flushes of the
+                       // fp32 accumulators into the fp64 second-level sums
 };
 
 // ---------------------------------------------------------------------------
@@ -85,8 +87,32 @@ __global__ void pack_frag16_f32(const double* __restrict__ F, int64_t ldF, int64
   }
 }
 
-template <int NT, bool EX>
+// Sum over the four 16-lane quarters of a wave of FOUR values at once, dealt out: quarter q of the result holds the
+// total of value q (lanes l, l^16, l^32, l^48 hold partial sums of the same rows).  gfx950's half-exchange permutes do it
+// in 3 swaps + 3 adds: v_permlane16_swap (odd rows of the first operand <-> even rows of the second) on (a, b) and
+// (c, d), then v_permlane32_swap (upper half of the first <-> lower half of the second) on the two sums.
+__device__ __forceinline__ float quarter_sum4(float a, float b, float c, float d) {
+  const auto ab = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  const auto cd = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), __float_as_uint(d), false, false);
+  const float s_ab = __uint_as_float(ab[0]) + __uint_as_float(ab[1]);   // rows: a01, b01, a23, b23
+  const float s_cd = __uint_as_float(cd[0]) + __uint_as_float(cd[1]);   // rows: c01, d01, c23, d23
+  const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(s_ab), __float_as_uint(s_cd), false, false);
+  return __uint_as_float(x[0]) + __uint_as_float(x[1]);                 // rows: a, b, c, d
+}
+
+// L2 (NT = 1 only, i.e. R <= 20: the headline rank): two-level accumulation.  The MFMA adds into an fp32 accumulator;
+// a run of 500 dependent adds (2000 columns) leaves a relative error of ~13 * 2^-24 in an entry of T, which after the
+// reductions and 25 outer iterations showed as 2e-8..6e-8 in the factors against the fp64 tensor mode -- outside the
+// 1e-8 of north_star.  With L2 the fp32 accumulators are flushed every `flush_every` loop rounds (default 3 = 72
+// columns = 18 adds) into fp64 sums and cleared: the 32 MFMA accumulators of a lane into the wave's own 16 KB slice of
+// LDS ([acc index][lane] doubles, conflict-free), the 32 packed-FMA accumulators of the leftover columns are first added over the four k-quarters
+// of the wave (quarter_sum4) and then into 8 fp64 registers (the VGPR budget at two waves per SIMD, 256, has no room
+// for 64 more register pairs: the kernel uses 202).
+// What is left is the rounding of the finished sum to the fp32 entry of T (2^-25 relative, independent per entry).
+// The flush is ~130 VALU/LDS instructions per 144 MFMAs of a wave and overlaps with the other wave's matrix work.
+template <int NT, bool EX, bool L2 = false>
 __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract16_f32(KArgs a) {
+  static_assert(!L2 || NT == 1, "two-level accumulation exists for one 16-column tile (R <= 20)");
   const int lane = threadIdx.x & 63;
   const int64_t wt = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wt >= a.ntiles) return;                       // wave-uniform
@@ -124,6 +150,40 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract16_f32(KArgs a) 
       for (int nt = 0; nt < NT; ++nt) acc[nt][h][v] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+  // second-level sums (L2): [(h*4 + v)*4 + i][lane] doubles in the wave's 16 KB LDS slice; leftover columns in registers
+  extern __shared__ __attribute__((aligned(16))) float t_lds[];
+  double* l2 = reinterpret_cast<double*>(t_lds) + (threadIdx.x >> 6) * 2048 + lane;
+  double accE2[2][4];                                 // lane (r16, q): row 64h + 4 r16 + v, leftover column q
+  if (L2) {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) l2[k * 64] = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) accE2[h][v] = 0.0;
+  }
+  // eight accumulators per batch (sched_barrier in between): all 32 LDS reads at once would need 64 more registers
+#define AO_FLUSH()                                                                                   \
+  {                                                                                                  \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                  \
+      _Pragma("unroll") for (int vb = 0; vb < 4; vb += 2) {                                          \
+        _Pragma("unroll") for (int v = vb; v < vb + 2; ++v)                                          \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+            l2[((h * 4 + v) * 4 + i) * 64] += (double)acc[0][h][v][i];                               \
+            acc[0][h][v][i] = 0.f;                                                                   \
+          }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+      }                                                                                              \
+    }                                                                                                \
+    if (EX) {      /* the four k-quarters of a row's four leftover columns, added and dealt out: quarter q keeps column q */ \
+      _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                  \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                              \
+          accE2[h][v] += (double)quarter_sum4(accE[h][v][0][0], accE[h][v][0][1], accE[h][v][1][0], accE[h][v][1][1]); \
+          accE[h][v][0] = f32x2{0.f, 0.f};                                                           \
+          accE[h][v][1] = f32x2{0.f, 0.f};                                                           \
+        }                                                                                            \
+    }                                                                                                \
+  }
   // register ring of three 8-column stages; x index s = 2*kk + half
   f32x4 x0[4], x1[4], x2[4], e0[2], e1[2], e2[2];
   f32x2 f0[NT], f1[NT], f2[NT];
@@ -166,10 +226,15 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract16_f32(KArgs a) 
   if (ng > 0) AO_LOAD_STAGE(x0, f0, e0, 0)
   if (ng > 1) AO_LOAD_STAGE(x1, f1, e1, 1)
   int64_t g = 0;
+  int since_flush = 0;
   for (; g + 5 <= ng; g += 3) {                      // steady state: every prefetch is in range
     AO_MIX_STAGE(x0, f0, e0, x2, f2, e2, g + 2)
     AO_MIX_STAGE(x1, f1, e1, x0, f0, e0, g + 3)
     AO_MIX_STAGE(x2, f2, e2, x1, f1, e1, g + 4)
+    if (L2 && ++since_flush == a.flush_every) {      // the next stages' loads are in flight behind this
+      since_flush = 0;
+      AO_FLUSH()
+    }
   }
   for (; g + 3 <= ng; g += 3) {                      // at most one drained round
     if (g + 2 < ng) AO_LOAD_STAGE(x2, f2, e2, g + 2)
@@ -201,6 +266,8 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract16_f32(KArgs a) 
     }
     AO_COMPUTE_STAGE(x0, f0, e0)
   }
+  if (L2) AO_FLUSH()
+#undef AO_FLUSH
 #undef AO_PKFMA_LO
 #undef AO_PKFMA_HI
 #undef AO_LOAD1
@@ -215,8 +282,20 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract16_f32(KArgs a) 
   // C/D registers directly -- 4-byte stores, 64-byte pieces of 80-byte rows -- cost 0.4-1.1 ms of a 5.3 ms pass at
   // 2000^3: partial lines are read-modified-written in L2 and trickle into HBM between the reads, and how much that
   // hurts depends on where X and T happen to lie; tools/micro/pass_placement.hip)
-  extern __shared__ __attribute__((aligned(16))) float t_lds[];
-  float* tl = t_lds + (threadIdx.x >> 6) * (kTileRows * a.R);
+  // (with L2 the wave's T tile takes the place of its second-level sums: 128*R*4 <= 16 KB, read out completely first)
+  float* tl = L2 ? t_lds + (threadIdx.x >> 6) * 4096 : t_lds + (threadIdx.x >> 6) * (kTileRows * a.R);
+  if (L2) {
+    double d2[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) d2[k] = l2[k * 64];
+    __builtin_amdgcn_sched_barrier(0);               // every read of the sums before the first write of the tile
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[0][h][v][i] = (float)d2[(h * 4 + v) * 4 + i];
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int r = 16 * nt + r16;
@@ -237,13 +316,21 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void contract16_f32(KArgs a) 
       for (int v = 0; v < 4; ++v)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+          if (L2) continue;                            // already added over the quarters at every flush
           float t = accE[h][v][e >> 1][e & 1];
           t += __shfl_xor(t, 16);
           t += __shfl_xor(t, 32);
           accE[h][v][e >> 1][e & 1] = t;
         }
-    if (q == 0) {
-      const int ne = a.R - 16 * NT;                  // 1..4 live extra columns
+    const int ne = a.R - 16 * NT;                    // 1..4 live extra columns
+    if (L2) {
+      if (q < ne) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) tl[(64 * h + 4 * r16 + v) * a.R + 16 * NT + q] = (float)accE2[h][v];
+      }
+    } else if (q == 0) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -771,9 +858,17 @@ void launch_contract(const void* X, int prec, const ContractPlan& pl, const doub
     const int64_t total = (int64_t)nt16 * Cg * 128 + (ex ? Cg * 32 : 0);
     pack_frag16_f32<<<(unsigned)cdiv(total, 256), 256, 0, s>>>(F, ldF, pl.C, pl.R, nt16, ex ? 1 : 0, Cg, (float*)frag_ws);
     AO_KERNEL_CHECK();
-    const size_t tsh = (size_t)4 * kTileRows * pl.R * sizeof(float);   // T tile of each of the four waves
+    size_t tsh = (size_t)4 * kTileRows * pl.R * sizeof(float);   // T tile of each of the four waves
+    // two-level accumulation for R <= 20 (see the kernel); AOADMM_CONTRACT_FLUSH = rounds of 24 columns between
+    // flushes (development switch; 0 = single-level fp32 accumulation as in rounds 1-2)
+    static const int flush_every = [] { const char* e = getenv("AOADMM_CONTRACT_FLUSH"); return e ? atoi(e) : 3; }();
+    a.flush_every = flush_every;
+    const bool l2 = nt16 == 1 && flush_every > 0;
+    if (l2) tsh = (size_t)4 * 16384;
 #define AO_GO(K) { if (tsh > 65536) ensure_dynamic_lds(reinterpret_cast<const void*>(K), (int)tsh); if (ev0) AO_HIP(hipEventRecord(ev0, s)); K<<<grid, 256, tsh, s>>>(a); }
-    if (nt16 == 1 && !ex) AO_GO((contract16_f32<1, false>))
+    if (l2 && !ex) AO_GO((contract16_f32<1, false, true>))
+    else if (l2) AO_GO((contract16_f32<1, true, true>))
+    else if (nt16 == 1 && !ex) AO_GO((contract16_f32<1, false>))
     else if (nt16 == 1) AO_GO((contract16_f32<1, true>))
     else if (nt16 == 2 && !ex) AO_GO((contract16_f32<2, false>))
     else if (nt16 == 2) AO_GO((contract16_f32<2, true>))

@@ -200,7 +200,7 @@ class Engine {
   void kernel_stats(int which, int reset, double* ms, int64_t* launches, double* bytes, double* flops);
 
   // communicator
-  void comm_init(const char id[128], int rank, int world);
+  void comm_init(const char id[128], int rank, int world, bool share_only = false);
   void comm_init_local(int key, int rank, int world);
   // Unblocks this engine's collectives after a failure on ANOTHER rank of the same process (aoadmm_create_multi):
   // callable from a foreign thread while the engine's own thread waits inside a collective; the next collective
@@ -209,7 +209,10 @@ class Engine {
   void comm_info(int* nccl_version, int* comm_ranks, char* lib_path, int cap) const;
   void set_progress(aoadmm_progress_fn fn, void* user, int every) { progress_fn_ = fn; progress_user_ = user; progress_every_ = every; }
   void par2_gather_slabs(TensorInfo& t);
-  bool sharded() const { return comm_ != nullptr || local_ != nullptr; }
+  // (world_ > 1 stays true after an abort took the communicator away: the engine must not fall back to unsharded work)
+  bool sharded() const { return world_ > 1 || comm_ != nullptr || local_ != nullptr; }
+  void require_usable() const;          // throws AOADMM_ERR_RCCL once comm_abort() has run (sticky)
+  bool share_only() const { return share_only_; }
   // tiny unsharded block: MTTKRP by the one-launch kernel instead of contraction pass + reduction
   bool small_direct(const CpBlock& b, int R) const { return !sharded() && small_mttkrp_ok(b.X.elems_padded(), b.nd, b.dims, R); }
   int rank() const { return rank_; }
@@ -299,6 +302,7 @@ class Engine {
   std::atomic<bool> aborted_{false};
   std::shared_ptr<LocalGroup> local_;   // process-local group (threads of one process), see solver.hip
   int rank_ = 0, world_ = 1;
+  bool share_only_ = false;             // aoadmm_comm_init_rank_share: rank_/world_ of an N-rank job on a one-rank communicator
   aoadmm_progress_fn progress_fn_ = nullptr;   // options.Display = 'iter'
   void* progress_user_ = nullptr;
   int progress_every_ = 0;

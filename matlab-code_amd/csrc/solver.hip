@@ -62,7 +62,7 @@ Engine::~Engine() {
 // ---------------------------------------------------------------------------
 // communicator
 // ---------------------------------------------------------------------------
-void Engine::comm_init(const char id[128], int rank, int world) {
+void Engine::comm_init(const char id[128], int rank, int world, bool share_only) {
   AO_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank/world %d/%d", rank, world);
   AO_REQUIRE(id != nullptr || world == 1, "a communicator of %d ranks needs the id from aoadmm_comm_unique_id", world);
   AO_HIP(hipSetDevice(device_));
@@ -72,10 +72,15 @@ void Engine::comm_init(const char id[128], int rank, int world) {
     ncclUniqueId uid;
     static_assert(sizeof(uid) <= 128, "unique id larger than the ABI buffer");
     std::memcpy(&uid, id, sizeof(uid));
-    AO_NCCL(ncclCommInitRank(&comm_, world, uid, rank));
+    // share_only (aoadmm_comm_init_rank_share): this engine takes rank `rank` of `world` in every sharding decision
+    // but its communicator has ONE rank, so the collectives run (ncclAllReduce on the library's stream) without
+    // peers: one rank's share of an N-GPU job, timed on a one-GPU box.  The sums are this rank's partial sums only.
+    if (share_only) AO_NCCL(ncclCommInitRank(&comm_, 1, uid, 0));
+    else AO_NCCL(ncclCommInitRank(&comm_, world, uid, rank));
   }
   rank_ = rank;
   world_ = world;
+  share_only_ = share_only;
   aborted_ = false;
 }
 
@@ -133,13 +138,20 @@ void Engine::comm_init_local(int key, int rank, int world) {
 }
 
 void Engine::comm_abort() {
-  aborted_ = true;
+  aborted_ = true;                              // sticky: every later collective, solve or upload of this engine throws
   if (local_) local_->abort();
-  std::lock_guard<std::mutex> lk(comm_mu_);
-  if (comm_) {
-    (void)ncclCommAbort(comm_);                 // the collective kernels of this rank see the flag and exit
+  ncclComm_t c = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(comm_mu_);
+    c = comm_;
     comm_ = nullptr;
   }
+  // outside the lock: the owner thread may sit inside ncclAllReduce's enqueue with a copy of the handle
+  if (c) (void)ncclCommAbort(c);                // the collective kernels of this rank see the flag and exit
+}
+
+void Engine::require_usable() const {
+  if (aborted_) throw Error(AOADMM_ERR_RCCL, "context unusable: its communicator was aborted after a failure on another rank");
 }
 
 void Engine::comm_info(int* nccl_version, int* comm_ranks, char* lib_path, int cap) const {
@@ -185,9 +197,19 @@ void Engine::allreduce(double* buf, int64_t n) {
     AO_HIP(hipStreamSynchronize(stream_));
     return;
   }
-  std::lock_guard<std::mutex> lk(comm_mu_);
-  if (!comm_) return;
-  AO_NCCL(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, comm_, stream_));
+  ncclComm_t c = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(comm_mu_);
+    if (aborted_) throw Error(AOADMM_ERR_RCCL, "communicator aborted after a failure on another rank");
+    c = comm_;
+  }
+  if (!c) {
+    // a sharded engine without a transport would go on with its partial sums: never silently
+    if (world_ > 1) throw Error(AOADMM_ERR_RCCL, fmt("rank %d of %d has no communicator", rank_, world_));
+    return;
+  }
+  // enqueued outside the lock so that comm_abort() from the caller's thread never waits behind a stuck enqueue
+  AO_NCCL(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, c, stream_));
 }
 
 // ---------------------------------------------------------------------------
@@ -555,6 +577,7 @@ void Engine::block_upload(CpBlock& b, int nd, const int64_t* dims, const double*
 }
 
 void Engine::tensor_upload(int p, const double* data, int prec, int64_t row0, int64_t local_rows) {
+  require_usable();
   AO_REQUIRE(model_done_, "call aoadmm_model_end first");
   AO_REQUIRE(p >= 0 && p < n_tensors_, "tensor %d out of range", p);
   TensorInfo& t = tensors_[p];
@@ -586,6 +609,7 @@ void Engine::tensor_upload(int p, const double* data, int prec, int64_t row0, in
 }
 
 double Engine::tensor_normsq(int p) {
+  require_usable();
   AO_REQUIRE(p >= 0 && p < n_tensors_, "tensor %d out of range", p);
   // test hook (tests/test_gpu_sharded.py): AOADMM_FAULT_INJECT=normsq:<rank> makes that rank fail ALONE in front of
   // a collective, the situation MultiCtx::run's abort path exists for (a device error or OOM on one GPU)
@@ -626,6 +650,7 @@ double Engine::tensor_normsq(int p) {
 }
 
 void Engine::tensor_synth(int p, int rank, uint64_t seed, double noise, int prec) {
+  require_usable();
   AO_REQUIRE(model_done_, "call aoadmm_model_end first");
   AO_REQUIRE(p >= 0 && p < n_tensors_, "tensor %d out of range", p);
   TensorInfo& t = tensors_[p];
@@ -688,6 +713,7 @@ void Engine::tensor_synth(int p, int rank, uint64_t seed, double noise, int prec
 // missing data (Z.miss, cmtf_AOADMM.m:68-121)
 // ---------------------------------------------------------------------------
 void Engine::tensor_mask_upload(int p, const uint8_t* mask) {
+  require_usable();
   AO_REQUIRE(p >= 0 && p < n_tensors_ && !tensors_[p].par2, "tensor %d is not a CP block", p);
   AO_REQUIRE(mask != nullptr, "null mask");
   TensorInfo& t = tensors_[p];
@@ -2888,6 +2914,7 @@ static bool stop_one(double f, double fo, const aoadmm_options& o) {
 }
 
 void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
+  require_usable();
   AO_REQUIRE(model_done_, "call aoadmm_model_end first");
   AO_REQUIRE(out != nullptr, "null result");
   AO_REQUIRE(opt.MaxOuterIters >= 0 && opt.MaxInnerIters >= 1, "bad iteration limits");

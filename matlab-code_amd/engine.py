@@ -88,6 +88,10 @@ class Engine:
     def comm_init_rank(self, uid, rank, world):
         capi.check(self.lib.aoadmm_comm_init_rank(self.h, uid, int(rank), int(world)))
 
+    def comm_init_rank_share(self, uid, rank, world):
+        """Measurement hook: rank `rank` of `world` in every sharding decision, on a ONE-rank RCCL communicator."""
+        capi.check(self.lib.aoadmm_comm_init_rank_share(self.h, uid, int(rank), int(world)))
+
     def comm_rank(self):
         """(rank, world) of this engine's communicator; (0, 1) without one."""
         r, w = C.c_int(0), C.c_int(1)

@@ -7,6 +7,9 @@
   script11_expected.npz  the oracle's output for the script-11 model on that data set: fixed init (stored), 40 outer
                          iterations with all tolerances 0 (fixed work), every factor and the objective history
 
+  known_answers.npz      (`--known-answers`; no reference file involved) generating factors and init structs of the four
+                         script-shaped known-answer cases of known_answers.py; `--export-mat DIR` also writes them as .mat
+
 The fixtures are data only; nothing of the reference's source is stored.  tests/test_golden.py checks that the
 oracle still reproduces script11_expected.npz, that a longer run recovers the ground-truth factors (known answer),
 and -- on the GPU -- that the HIP path reproduces the same numbers.
@@ -72,7 +75,36 @@ def unpack_G(d, prefix=''):
             'mu_DeltaB': {0: [g('mu_DeltaB')[k].copy() for k in range(K)]}}
 
 
+def known_answers_main(export_mat=None):
+    """tests/golden/known_answers.npz: generating factors (+ the noisy tensor of script 10) and the init struct of the four
+    script-shaped known-answer cases (known_answers.py).  `export_mat`: directory for <case>.mat files holding the same
+    arrays plus the model's data, for matlab-code_amd/mex/parity_known_answers.m."""
+    import known_answers as KA
+    store = {}
+    for name in KA.CASES:
+        t, Z, norms, G, opt = KA.build_case(name)
+        for k, v in t.items():
+            store['%s/truth_%s' % (name, k)] = np.asarray(v)
+        for k, v in KA.pack_state(G).items():
+            store['%s/init_%s' % (name, k)] = v
+        if export_mat:
+            os.makedirs(export_mat, exist_ok=True)
+            m = {'truth_' + k: np.asarray(v) for k, v in t.items()}
+            m.update({'init_' + k: v for k, v in KA.pack_state(G).items()})
+            for p, obj in enumerate(Z['object']):
+                m['object_%d' % (p + 1)] = np.stack(obj) if isinstance(obj, list) else np.asarray(obj)
+            m['options'] = {k: v for k, v in opt.items()}
+            sio.savemat(os.path.join(export_mat, name + '.mat'), m, do_compression=True)
+    np.savez_compressed(os.path.join(HERE, 'known_answers.npz'), **store)
+    print('wrote known_answers.npz (%d arrays)' % len(store))
+
+
 def main():
+    if '--known-answers' in sys.argv or '--export-mat' in sys.argv:
+        d = sys.argv[sys.argv.index('--export-mat') + 1] if '--export-mat' in sys.argv else None
+        sys.path.insert(0, HERE)
+        known_answers_main(d)
+        return
     from oracle import aoadmm as OA
     ds = sio.loadmat(os.path.join(REF, 'noisy_dataset.mat'))['dataset'].astype(np.float64)
     gnd = sio.loadmat(os.path.join(REF, 'gnd_factors.mat'))

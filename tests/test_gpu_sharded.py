@@ -274,8 +274,16 @@ def test_multi_device_lone_failure_does_not_hang(pkg, monkeypatch):
     with pkg.Engine([0, 0, 0]) as e:
         with pytest.raises(capi.AoadmmError) as ei:
             pkg.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=3), init=copy.deepcopy(G), engine=e)
-    assert 'rank 1' in str(ei.value) and 'injected fault' in str(ei.value)
-    assert time.time() - t0 < 60
+        assert 'rank 1' in str(ei.value) and 'injected fault' in str(ei.value)
+        assert time.time() - t0 < 60
+        # the context is poisoned for good: the aborted ranks would skip collectives the failed rank still enters, so
+        # every later call fails at once (no second grace period, no silent unsharded work)
+        monkeypatch.delenv('AOADMM_FAULT_INJECT')
+        t1 = time.time()
+        with pytest.raises(capi.AoadmmError) as ej:
+            pkg.cmtf_AOADMM(Z, alg_options=options(MaxOuterIters=1), init=copy.deepcopy(G), engine=e)
+        assert ej.value.code == capi.ERR_RCCL and 'unusable' in str(ej.value)
+        assert time.time() - t1 < 2
 
 
 def test_op_level_calls_on_a_multi_device_context(pkg):
