@@ -256,6 +256,12 @@ int aoadmm_op_mttkrp(aoadmm_ctx* ctx, const double* X, int ndims, const int64_t*
  * (MATLAB `eigs`, numpy `eigh`). */
 int aoadmm_op_unfold_gram(aoadmm_ctx* ctx, const double* X, int ndims, const int64_t* dims, int n, int precision,
                           double* out);
+/* The same Gram matrix from the RESIDENT data of tensor p (uploaded or generated before): no second transfer of the
+ * tensor for init_options.nvecs = 1 (cmtf_nvecs.m:31-56 unfolds the data it already holds).  CP blocks: tensor_mode
+ * 0..2, slab ignored; PARAFAC2 blocks: tensor_mode 0 (all slabs side by side) or 1 (slab `slab`).  With a communicator
+ * the partial sums of the row blocks are all-reduced; the first mode of a row-sharded block has no local answer:
+ * AOADMM_ERR_UNSUPPORTED (use aoadmm_op_unfold_gram with the host array). */
+int aoadmm_resident_unfold_gram(aoadmm_ctx* ctx, int p, int tensor_mode, int slab, double* out);
 /* G'*G : cmtf_fun_AOADMM.m:66,148 */
 int aoadmm_op_gram(aoadmm_ctx* ctx, const double* F, int64_t rows, int R, double* out);
 /* L = chol(B','lower') : cmtf_fun_AOADMM.m:142 ; AOADMM_ERR_NOT_PD on failure */

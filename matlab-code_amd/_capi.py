@@ -30,7 +30,7 @@ SYMBOLS = [
     'aoadmm_model_set_coupling_type', 'aoadmm_model_set_ridge', 'aoadmm_model_end', 'aoadmm_tensor_upload',
     'aoadmm_tensor_upload_rows', 'aoadmm_par2_slab_upload', 'aoadmm_tensor_mask_upload', 'aoadmm_par2_slab_mask_upload', 'aoadmm_tensor_synth', 'aoadmm_tensor_normsq',
     'aoadmm_state_set', 'aoadmm_state_get', 'aoadmm_solve', 'aoadmm_resident_mttkrp', 'aoadmm_kernel_stats',
-    'aoadmm_op_mttkrp', 'aoadmm_op_unfold_gram', 'aoadmm_op_gram', 'aoadmm_op_chol', 'aoadmm_op_prox', 'aoadmm_op_admm_constrained',
+    'aoadmm_op_mttkrp', 'aoadmm_op_unfold_gram', 'aoadmm_resident_unfold_gram', 'aoadmm_op_gram', 'aoadmm_op_chol', 'aoadmm_op_prox', 'aoadmm_op_admm_constrained',
 ]
 
 
@@ -126,6 +126,7 @@ def load_library():
     lib.aoadmm_kernel_stats.argtypes = [vp, C.c_int, C.c_int, dp, C.POINTER(i64), dp, dp]
     lib.aoadmm_op_mttkrp.argtypes = [vp, dp, C.c_int, C.POINTER(i64), C.POINTER(dp), C.c_int, C.c_int, C.c_int, dp]
     lib.aoadmm_op_unfold_gram.argtypes = [vp, dp, C.c_int, C.POINTER(i64), C.c_int, C.c_int, dp]
+    lib.aoadmm_resident_unfold_gram.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     lib.aoadmm_op_gram.argtypes = [vp, dp, i64, C.c_int, dp]
     lib.aoadmm_op_chol.argtypes = [vp, dp, C.c_int, dp]
     lib.aoadmm_op_prox.argtypes = [vp, C.c_int, dp, C.c_int, dp, dp, i64, C.c_int, C.c_double, dp]

@@ -22,23 +22,25 @@ struct ProxSpec {
 // 'quadratic regularization' (constraints_to_prox.m:62-67): prox(x,rho) = (2*eta/rho*L + I) \ x with a fixed
 // user matrix L.  rho changes every outer iteration, L does not: L is diagonalised once on the host
 // (symmetric L required) and the prox becomes U * diag(1/(2*eta/rho*w_i + 1)) * U' * x, two small GEMMs.
-// A non-symmetric L has no orthogonal eigenbasis: the host keeps L, and whenever 2*eta/rho differs from the value
-// the cached inverse was built for (once per outer iteration: rho is fixed inside an inner loop) it inverts
-// 2*eta/rho*L + I by Gauss-Jordan elimination with partial pivoting (what MATLAB's `\` pivots on) and uploads the
-// inverse; the prox is then one small GEMM.  The reference factorises the same matrix in EVERY prox call.
+// A non-symmetric L has no orthogonal eigenbasis: whenever 2*eta/rho may have moved (once per outer iteration: rho is
+// fixed inside an inner loop; the engine sets `dirty`) the prox inverts 2*eta/rho*L + I ON THE DEVICE by Gauss-Jordan
+// elimination with row pivoting (what MATLAB's `\` pivots on; admm.hip quad_gj_step_k, rho read from device memory, no
+// host synchronisation) and is then one small GEMM.  The reference factorises the same matrix in EVERY prox call.
 struct QuadPrep {
   DevBuf L, U, Ut, w;
-  DevBuf Minv;                     // non-symmetric L: (g*L + I)^-1, column-major
-  std::vector<double> Lh;          // non-symmetric L: host copy (column-major, as passed)
+  DevBuf Minv, Mwork, piv, pval;   // non-symmetric L: the two buffers the elimination alternates between, pivot rows, pivot value
   bool nonsym = false;
-  double g_cached = -1.0;
+  bool dirty = true;               // the cached inverse may belong to another rho
+  const double* key_rho = nullptr; // what the cached inverse was built for
+  double key_mul = 0.0, key_eta = 0.0;
+  const double* result = nullptr;
   int64_t n = 0;
   void build(const double* L_host, int64_t rows, hipStream_t s);
   void attach(ProxSpec& ps) {
     ps.Lmat = L.d(); ps.LU = U.d(); ps.LUt = Ut.d(); ps.Lw = w.d();
     ps.quad = nonsym ? this : nullptr;
   }
-  // reads rho from the device (a stream synchronisation), rebuilds Minv if g = 2*eta/(rho*rho_mul) changed
+  // (g*L + I)^-1 for g = 2*eta/(rho*rho_mul), column-major n x n on the device; rebuilt when dirty or asked for another rho
   const double* refresh(double eta, const double* rho_dev, double rho_mul, hipStream_t s);
 };
 

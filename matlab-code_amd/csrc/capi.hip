@@ -522,6 +522,15 @@ int aoadmm_op_unfold_gram(aoadmm_ctx* ctx, const double* X, int ndims, const int
   });
 }
 
+int aoadmm_resident_unfold_gram(aoadmm_ctx* ctx, int p, int tensor_mode, int slab, double* out) {
+  CTX_OR_FAIL(ctx);
+  return guarded([&] {
+    AO_REQUIRE(out != nullptr, "null pointer");
+    // every engine of a multi-device context enters (the Gram matrix of a sharded block is all-reduced); rank 0 reports
+    on_engines(ctx, [&](Engine& e, int r) { e.resident_unfold_gram(p, tensor_mode, slab, r == 0 ? out : nullptr); });
+  });
+}
+
 int aoadmm_op_gram(aoadmm_ctx* ctx, const double* F, int64_t rows, int R, double* out) {
   CTX_OR_FAIL(ctx);
   return guarded([&] {

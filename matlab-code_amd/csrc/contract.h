@@ -60,18 +60,23 @@ void launch_contract(const void* X, int prec, const ContractPlan& pl, const doub
 // out(b,r) = scale * sum_a sum_chunk T[chunk][a + Apad*b][r] * Fa(a,r)      (a < A)
 // ft_scratch: reduce_factor_scratch_bytes(A, R) (row-major copy of the factor)
 size_t reduce_factor_scratch_bytes(int64_t rows, int R);
-void launch_reduce_inner(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
+// `sys` (both reductions, optional): the R x R system build of the mode whose MTTKRP this reduction finishes rides in the
+// launch as one extra workgroup (small_dev.h: it needs Gram matrices only, so it runs beside the reduction instead of
+// behind it).  Returns true when it did (R <= 20); otherwise the caller launches sys_build itself.
+struct SysBuild;
+bool launch_reduce_inner(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
                          int64_t B, int R, const double* Fa, int64_t ldFa, double scale,
                          double* out, int64_t ldOut, double* ft_scratch, hipStream_t s,
                          const double* FaT = nullptr,    // FaT: row-major copy of Fa if the caller keeps one
-                         int rowmajor_out = 0);          // 1: out is [b][r] (T layout, for a further fold)
+                         int rowmajor_out = 0,           // 1: out is [b][r] (T layout, for a further fold)
+                         const SysBuild* sys = nullptr);
 // out(a,r) = scale * sum_b sum_chunk T[chunk][a + Apad*b][r] * Fb(b,r)      (a < A)
 // scratch must hold reduce_outer_scratch_bytes(); ft_scratch reduce_factor_scratch_bytes(B, R).
 size_t reduce_outer_scratch_bytes(int64_t A, int64_t B, int R);
-void launch_reduce_outer(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
+bool launch_reduce_outer(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
                          int64_t B, int R, const double* Fb, int64_t ldFb, double scale,
                          double* out, int64_t ldOut, double* scratch, double* ft_scratch, hipStream_t s,
-                         const double* FbT = nullptr, int rowmajor_out = 0);
+                         const double* FbT = nullptr, int rowmajor_out = 0, const SysBuild* sys = nullptr);
 // out(a,r) = scale * sum_chunk T[chunk][a][r]     (matrix blocks: nothing left to reduce)
 void launch_t_to_colmajor(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int R, double scale,
                           double* out, int64_t ldOut, hipStream_t s);

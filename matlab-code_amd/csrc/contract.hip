@@ -22,6 +22,7 @@
 //      5.2 ms for 16 MFMA columns + 4 on the vector pipe.)
 #include "contract.h"
 #include "device_utils.h"
+#include "small_dev.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -967,9 +968,12 @@ struct RVec {
 template <typename TT, int VEC>
 __global__ void reduce_inner_k(const TT* __restrict__ T, int nchunk, int64_t trows, int64_t A, int64_t Apad, int R,
                                const double* __restrict__ FaT, double scale, double* __restrict__ out,
-                               int64_t ldOut, int rowmajor) {
+                               int64_t ldOut, int rowmajor, int has_sys, SysBuild sys) {
   extern __shared__ double sh[];                      // blockDim * VEC
-  const int64_t b = blockIdx.x;
+  // the extra workgroup (small_dev.h) is the FIRST one: dispatched first, its 10 us of dependent latency run beside the
+  // reduction (as the last workgroup it started when the others were nearly through and lengthened the kernel by 6-12 us)
+  if (has_sys && blockIdx.x == 0) { sys_build_rider(sys); return; }
+  const int64_t b = (int64_t)blockIdx.x - has_sys;
   const int t = threadIdx.x;
   const int64_t n = A * R, step = (int64_t)blockDim.x * VEC;
   double s0[VEC], s1[VEC], s2[VEC], s3[VEC];
@@ -1006,9 +1010,10 @@ __global__ void reduce_inner_k(const TT* __restrict__ T, int nchunk, int64_t tro
 template <typename TT, int VEC>
 __global__ void reduce_inner2_k(const TT* __restrict__ T, int nchunk, int64_t trows, int64_t A, int64_t Apad, int64_t B,
                                 int R, const double* __restrict__ FaT, double scale, double* __restrict__ out,
-                                int64_t ldOut, int rowmajor) {
+                                int64_t ldOut, int rowmajor, int has_sys, SysBuild sys) {
   extern __shared__ double sh[];                      // 2 * blockDim * VEC
-  const int64_t b0 = 2 * (int64_t)blockIdx.x;
+  if (has_sys && blockIdx.x == 0) { sys_build_rider(sys); return; }   // the extra workgroup, dispatched first (see reduce_inner_k)
+  const int64_t b0 = 2 * ((int64_t)blockIdx.x - has_sys);
   const bool two = b0 + 1 < B;
   const int64_t b1 = two ? b0 + 1 : b0;
   const int t = threadIdx.x;
@@ -1061,36 +1066,53 @@ size_t reduce_factor_scratch_bytes(int64_t rows, int R) { return (size_t)rows * 
 
 template <typename TT, int VEC>
 static void launch_inner_t(const void* T, int nchunk, int64_t trows, int64_t A, int64_t Apad, int64_t B, int R,
-                           const double* FaT, double scale, double* out, int64_t ldOut, hipStream_t s, int rowmajor) {
+                           const double* FaT, double scale, double* out, int64_t ldOut, hipStream_t s, int rowmajor,
+                           const SysBuild* sys) {
+  const int hs = sys ? 1 : 0;
+  const SysBuild sb = sys ? *sys : SysBuild();
   const int rq = R / VEC;                             // threads per row of T
   int threads = 256 / rq * rq;
   if (threads < rq) threads = rq;
   if (threads * VEC < R) threads = (R + VEC - 1) / VEC;
   if (B >= 1024 && 2 * R <= threads) {                // enough slabs to fill the chip with half as many blocks
-    reduce_inner2_k<TT, VEC><<<(unsigned)((B + 1) / 2), threads, (size_t)2 * threads * VEC * sizeof(double), s>>>(
-        (const TT*)T, nchunk, trows, A, Apad, B, R, FaT, scale, out, ldOut, rowmajor);
+    reduce_inner2_k<TT, VEC><<<(unsigned)((B + 1) / 2 + hs), threads, (size_t)2 * threads * VEC * sizeof(double), s>>>(
+        (const TT*)T, nchunk, trows, A, Apad, B, R, FaT, scale, out, ldOut, rowmajor, hs, sb);
     return;
   }
-  reduce_inner_k<TT, VEC><<<(unsigned)B, threads, (size_t)threads * VEC * sizeof(double), s>>>(
-      (const TT*)T, nchunk, trows, A, Apad, R, FaT, scale, out, ldOut, rowmajor);
+  reduce_inner_k<TT, VEC><<<(unsigned)(B + hs), threads, (size_t)threads * VEC * sizeof(double), s>>>(
+      (const TT*)T, nchunk, trows, A, Apad, R, FaT, scale, out, ldOut, rowmajor, hs, sb);
 }
 
-void launch_reduce_inner(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
+static bool sys_can_ride(const SysBuild* sys, int threads_min = 64) {
+  return sys != nullptr && sys->R >= 1 && sys->R <= kSysRiderMaxR && threads_min >= 64;
+}
+
+bool launch_reduce_inner(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
                          int64_t B, int R, const double* Fa, int64_t ldFa, double scale,
                          double* out, int64_t ldOut, double* ft_scratch, hipStream_t s, const double* FaT,
-                         int rowmajor_out) {
-  AO_REQUIRE((int64_t)B <= 2147483647ll, "reduce_inner: too many output rows for one launch");
+                         int rowmajor_out, const SysBuild* sys) {
+  AO_REQUIRE((int64_t)B < 2147483647ll, "reduce_inner: too many output rows for one launch");
+  // the rider needs one full wave in the extra workgroup: blocks here have >= R / VEC threads, 240-256 in practice
+  {
+    const int vec = tprec == AOADMM_PREC_F32 ? (R % 4 == 0 ? 4 : 1) : (R % 2 == 0 ? 2 : 1);
+    const int rq = R / vec;
+    int threads = 256 / rq * rq;
+    if (threads < rq) threads = rq;
+    if (threads * vec < R) threads = (R + vec - 1) / vec;
+    if (!sys_can_ride(sys, threads)) sys = nullptr;
+  }
   if (FaT) ft_scratch = const_cast<double*>(FaT);    // row-major copy already maintained by the caller
   else factor_rowmajor(Fa, ldFa, A, R, ft_scratch, s);
   // 16-byte loads need every slab (Apad*R elements) and every chunk (trows*R) to start 16-byte aligned
   if (tprec == AOADMM_PREC_F32) {
-    if (R % 4 == 0) launch_inner_t<float, 4>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s, rowmajor_out);
-    else launch_inner_t<float, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s, rowmajor_out);
+    if (R % 4 == 0) launch_inner_t<float, 4>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s, rowmajor_out, sys);
+    else launch_inner_t<float, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s, rowmajor_out, sys);
   } else {
-    if (R % 2 == 0) launch_inner_t<double, 2>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s, rowmajor_out);
-    else launch_inner_t<double, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s, rowmajor_out);
+    if (R % 2 == 0) launch_inner_t<double, 2>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s, rowmajor_out, sys);
+    else launch_inner_t<double, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scale, out, ldOut, s, rowmajor_out, sys);
   }
   AO_KERNEL_CHECK();
+  return sys != nullptr;
 }
 
 // out(a, r) = sum_b T[a + Apad*b][r] * Fb(b, r): block = TA consecutive rows a x (R/VEC) r-groups, grid.y
@@ -1124,11 +1146,15 @@ size_t reduce_outer_scratch_bytes(int64_t A, int64_t B, int R) {
 template <typename TT, int VEC>
 __global__ void reduce_outer_k(const TT* __restrict__ T, int nchunk, int64_t trows, int64_t A,
                                int64_t Apad, int64_t B, int R, int TA, const double* __restrict__ FbT,
-                               double* __restrict__ part) {
+                               double* __restrict__ part, int has_sys, SysBuild sys) {
+  if (has_sys && blockIdx.x == 0) {                   // the extra column of workgroups (dispatched first): one of them builds the system
+    if (blockIdx.y == 0) sys_build_rider(sys);
+    return;
+  }
   const int t = threadIdx.x;
   const int rq = R / VEC;
   const int al = t / rq, r = (t - al * rq) * VEC;
-  const int64_t a = (int64_t)blockIdx.x * TA + al;
+  const int64_t a = ((int64_t)blockIdx.x - has_sys) * TA + al;
   const int SB = gridDim.y, sb = blockIdx.y;
   const int64_t bper = (B + SB - 1) / SB;
   const int64_t b0 = sb * bper;
@@ -1187,33 +1213,36 @@ __global__ void reduce_outer_fin(const double* __restrict__ part, int SB, int64_
 
 template <typename TT, int VEC>
 static void launch_outer_t(const void* T, int nchunk, int64_t trows, int64_t A, int64_t Apad, int64_t B, int R,
-                           const double* FbT, double* scratch, int& SB, hipStream_t s) {
+                           const double* FbT, double* scratch, int& SB, hipStream_t s, const SysBuild* sys) {
   int TA; int64_t nb;
   outer_geometry(A, B, R, VEC, TA, nb, SB);
   int threads = TA * (R / VEC);
   threads = (threads + 63) / 64 * 64;
-  reduce_outer_k<TT, VEC><<<dim3((unsigned)nb, (unsigned)SB), threads, 0, s>>>((const TT*)T, nchunk, trows, A, Apad, B,
-                                                                             R, TA, FbT, scratch);
+  const int hs = sys ? 1 : 0;
+  reduce_outer_k<TT, VEC><<<dim3((unsigned)(nb + hs), (unsigned)SB), threads, 0, s>>>((const TT*)T, nchunk, trows, A, Apad, B,
+                                                                                    R, TA, FbT, scratch, hs, sys ? *sys : SysBuild());
 }
 
-void launch_reduce_outer(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
+bool launch_reduce_outer(const void* T, int tprec, int nchunk, int64_t trows, int64_t A, int64_t Apad,
                          int64_t B, int R, const double* Fb, int64_t ldFb, double scale,
                          double* out, int64_t ldOut, double* scratch, double* ft_scratch, hipStream_t s,
-                         const double* FbT, int rowmajor_out) {
+                         const double* FbT, int rowmajor_out, const SysBuild* sys) {
+  if (!sys_can_ride(sys)) sys = nullptr;
   if (FbT) ft_scratch = const_cast<double*>(FbT);
   else factor_rowmajor(Fb, ldFb, B, R, ft_scratch, s);
   int SB = 1;
   const int vec = outer_vec(tprec, R);
   if (tprec == AOADMM_PREC_F32) {
-    if (vec == 4) launch_outer_t<float, 4>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s);
-    else launch_outer_t<float, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s);
+    if (vec == 4) launch_outer_t<float, 4>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s, sys);
+    else launch_outer_t<float, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s, sys);
   } else {
-    if (vec == 2) launch_outer_t<double, 2>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s);
-    else launch_outer_t<double, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s);
+    if (vec == 2) launch_outer_t<double, 2>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s, sys);
+    else launch_outer_t<double, 1>(T, nchunk, trows, A, Apad, B, R, ft_scratch, scratch, SB, s, sys);
   }
   AO_KERNEL_CHECK();
   reduce_outer_fin<<<(unsigned)cdiv(A * R, 256), 256, 0, s>>>(scratch, SB, A, R, scale, out, ldOut, rowmajor_out);
   AO_KERNEL_CHECK();
+  return sys != nullptr;
 }
 
 // ---------------------------------------------------------------------------

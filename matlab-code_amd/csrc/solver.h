@@ -60,6 +60,11 @@ struct CpBlock {
   uint64_t cached_version = 0;
   ContractPlan plan;
   DevBuf T, frag, scratch, ft, tmpA, tmpB;
+  // sharded MTTKRP outputs that are this rank's ROWS of the result (mode 1; mode 3 under xp_ksharded): send buffers whose
+  // other rows are zero for good (cleared once), all-reduced out of place into the caller's buffer
+  DevBuf own[2];
+  size_t own_bytes[2] = {0, 0};
+  int64_t own_row0[2] = {-1, -1};
   // Z.miss{p}: one byte per entry in the layout of X (and of Xt for matrices), 1 = observed
   DevBuf mask, maskT;
   bool has_mask = false;
@@ -159,7 +164,7 @@ struct CouplingInfo {
 struct KernelStats {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   double ms = 0.0, bytes = 0.0, flops = 0.0;
-  int64_t launches = 0;
+  int64_t launches = 0, timed = 0;      // timed <= launches: launches bracketed by an event pair
 };
 
 struct LocalGroup;
@@ -197,6 +202,7 @@ class Engine {
   // solve
   void solve(const aoadmm_options& opt, aoadmm_result* out);
   void resident_mttkrp(int p, int pos, double* out_host, float* ms);
+  void resident_unfold_gram(int p, int pos, int slab, double* out_host);
   void kernel_stats(int which, int reset, double* ms, int64_t* launches, double* bytes, double* flops);
 
   // communicator
@@ -238,11 +244,12 @@ class Engine {
   // (the op-level entries, so that their parity tests exercise the pass kernels at every size)
   void block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
                     int64_t ldOut, bool use_cache, const int* update_seq, int nseq, bool collective = true,
-                    bool tensor_pass = false);
+                    bool tensor_pass = false, const SysBuild* sys = nullptr, bool* sys_done = nullptr);
   // `full_array`: the caller's whole tensor when it holds one (lets a sharded engine take its mode-3 slab as well)
   void block_upload(CpBlock& b, int nd, const int64_t* dims, const double* host, int prec, int64_t row0,
                     int64_t local_rows, const double* full_array = nullptr);
   void allreduce(double* buf, int64_t n);
+  void allreduce_from(const double* send, double* recv, int64_t n);   // out of place (send == recv: in place)
   double* scratch_slots() { return slots_.d(); }
   double* red_ws() { return redws_.d(); }
 
@@ -293,6 +300,7 @@ class Engine {
   DevBuf staging_;
   std::vector<hipEvent_t> event_pool_;   // timing events are recycled: creating two per tensor pass cost host time in the loop
   hipEvent_t take_event();
+  void fold_finished(KernelStats& ks);
   KernelStats kstats_[3];   // [0] streaming contraction, [1] leading-mode contraction, [2] reductions over T
   int prepared_mode_ = -1;  // mode whose MTTKRP + system build were enqueued ahead (prepare_next_first_mode)
   bool profile_ = true;

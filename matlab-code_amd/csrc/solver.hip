@@ -176,14 +176,17 @@ void Engine::comm_info(int* nccl_version, int* comm_ranks, char* lib_path, int c
   }
 }
 
-void Engine::allreduce(double* buf, int64_t n) {
+void Engine::allreduce(double* buf, int64_t n) { allreduce_from(buf, buf, n); }
+
+// recv = sum over ranks of send (send == recv: in place)
+void Engine::allreduce_from(const double* send, double* buf, int64_t n) {
   if (n <= 0) return;
   if (aborted_) throw Error(AOADMM_ERR_RCCL, "communicator aborted after a failure on another rank");
   if (local_) {
     LocalGroup& g = *local_;
     std::vector<double>& mine = g.stage[rank_];
     mine.resize((size_t)n);
-    AO_HIP(hipMemcpyAsync(mine.data(), buf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    AO_HIP(hipMemcpyAsync(mine.data(), send, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream_));
     AO_HIP(hipStreamSynchronize(stream_));
     g.barrier();                                // every rank has staged its contribution
     std::vector<double> tot((size_t)n, 0.0);
@@ -206,10 +209,11 @@ void Engine::allreduce(double* buf, int64_t n) {
   if (!c) {
     // a sharded engine without a transport would go on with its partial sums: never silently
     if (world_ > 1) throw Error(AOADMM_ERR_RCCL, fmt("rank %d of %d has no communicator", rank_, world_));
+    if (send != buf) AO_HIP(hipMemcpyAsync(buf, send, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     return;
   }
   // enqueued outside the lock so that comm_abort() from the caller's thread never waits behind a stuck enqueue
-  AO_NCCL(ncclAllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, c, stream_));
+  AO_NCCL(ncclAllReduce(send, buf, (size_t)n, ncclDouble, ncclSum, c, stream_));
 }
 
 // ---------------------------------------------------------------------------
@@ -989,15 +993,35 @@ void Engine::timed_contract(const void* X, int prec, const ContractPlan& pl, con
   KernelStats& ks = kstats_[pl.lead ? 1 : 0];
   hipEvent_t e0 = nullptr, e1 = nullptr;
   static const bool no_events = getenv("AOADMM_NO_PASS_EVENTS") != nullptr;   // development switch (tools/gap_analysis.py)
-  if (profile_ && !no_events && ks.pending.size() < 100000) {
-    e0 = take_event();
-    e1 = take_event();
+  if (profile_ && !no_events) {
+    if (ks.pending.size() >= 512) fold_finished(ks);     // a long solve never holds more than a few hundred events
+    if (ks.pending.size() < 4096) {
+      e0 = take_event();
+      e1 = take_event();
+    }
   }
   launch_contract(X, prec, pl, F, ldF, frag, T, stream_, e0, e1);
-  if (e0) ks.pending.emplace_back(e0, e1);
+  if (e0) { ks.pending.emplace_back(e0, e1); ks.timed++; }
   ks.launches++;
   ks.bytes += pl.algorithmic_bytes(prec);
   ks.flops += pl.flops();
+}
+
+// pairs whose second event has completed are added to ks.ms and their events go back to the pool (no synchronisation)
+void Engine::fold_finished(KernelStats& ks) {
+  size_t keep = 0;
+  for (size_t i = 0; i < ks.pending.size(); ++i) {
+    auto& pr = ks.pending[i];
+    float t = 0.f;
+    if (hipEventQuery(pr.second) == hipSuccess && hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) {
+      ks.ms += t;
+      event_pool_.push_back(pr.first);
+      event_pool_.push_back(pr.second);
+    } else {
+      ks.pending[keep++] = pr;
+    }
+  }
+  ks.pending.resize(keep);
 }
 
 void Engine::kernel_stats(int which, int reset, double* ms, int64_t* launches, double* bytes, double* flops) {
@@ -1014,11 +1038,13 @@ void Engine::kernel_stats(int which, int reset, double* ms, int64_t* launches, d
     event_pool_.push_back(pr.second);
   }
   ks.pending.clear();
-  if (ms) *ms = ks.ms;
+  // launches that went untimed (event budget exhausted) count at the mean of the timed ones, so ms / launches stays
+  // the mean launch duration
+  if (ms) *ms = (ks.timed > 0 && ks.timed < ks.launches) ? ks.ms * (double)ks.launches / (double)ks.timed : ks.ms;
   if (launches) *launches = ks.launches;
   if (bytes) *bytes = ks.bytes;
   if (flops) *flops = ks.flops;
-  if (reset) { ks.ms = 0; ks.launches = 0; ks.bytes = 0; ks.flops = 0; }
+  if (reset) { ks.ms = 0; ks.launches = 0; ks.timed = 0; ks.bytes = 0; ks.flops = 0; }
 }
 
 // distance (in updates) until tensor position `c` is updated again after position `pos`
@@ -1206,7 +1232,8 @@ bool Engine::prefetch_next_contraction(const aoadmm_options& opt) {
 
 void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, double scale, double* out,
                           int64_t ldOut, bool use_cache, const int* update_seq, int nseq, bool collective,
-                          bool tensor_pass) {
+                          bool tensor_pass, const SysBuild* sys, bool* sys_done) {
+  if (sys_done) *sys_done = false;
   AO_REQUIRE(b.has_data, "tensor has no data");
   AO_REQUIRE(pos >= 0 && pos < b.nd, "mttkrp: mode %d out of range", pos);
   const int prec = b.X.prec;
@@ -1214,12 +1241,26 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
   const bool sharded = collective && this->sharded();
   double* out_local = out;
   const int64_t out_rows_full = (pos == 0) ? b.full0 : b.dims[pos];
-  if (sharded && pos == 0) {
-    // every rank fills its own rows of a zeroed buffer; the all-reduce is the all-gather
-    for (int r = 0; r < R; ++r)
-      AO_HIP(hipMemsetAsync(out + ldOut * r, 0, (size_t)out_rows_full * sizeof(double), stream_));
-    out_local = out + b.row0;
-  }
+  // "Every rank fills its own rows of a zeroed buffer; the all-reduce is the all-gather": the zeroed buffer is a send
+  // buffer of the block that is cleared ONCE -- the rows of other ranks are never written, the own rows are overwritten
+  // by every MTTKRP -- and the all-reduce goes from it into `out` (a fill in front of every such MTTKRP was 5 us on the
+  // critical path, two per outer iteration).
+  const double* send = nullptr;
+  int64_t ld_local = ldOut;
+  auto own_rows_buffer = [&](int which, int64_t rows_full, int64_t row_first) {
+    DevBuf& ob = b.own[which];
+    const size_t need = (size_t)rows_full * R * sizeof(double);
+    if (b.own_bytes[which] != need || b.own_row0[which] != row_first) {    // (another rank's rows would stay behind)
+      if (b.own_bytes[which] != need) ob.alloc(need);
+      AO_HIP(hipMemsetAsync(ob.p, 0, need, stream_));
+      b.own_bytes[which] = need;
+      b.own_row0[which] = row_first;
+    }
+    send = ob.d();
+    ld_local = rows_full;
+    out_local = ob.d() + row_first;
+  };
+  if (sharded && pos == 0) own_rows_buffer(0, out_rows_full, b.row0);
   const double* F0 = facs[0].p + (sharded ? b.row0 : 0);     // local rows of the first factor
 
   if (!tensor_pass && small_direct(b, R)) {
@@ -1244,13 +1285,13 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
       ContractPlan pl = make_plan(1, 0, Ip, Ip, J, R, prec);
       b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
       timed_contract(b.X.data.p, prec, pl, facs[1].p, facs[1].ld, b.frag.p, b.T.p);
-      launch_t_to_colmajor(b.T.p, pl.tprec, pl.nchunk, pl.trows(), I, R, scale, out_local, ldOut, stream_);
+      launch_t_to_colmajor(b.T.p, pl.tprec, pl.nchunk, pl.trows(), I, R, scale, out_local, ld_local, stream_);
     } else {
       const int64_t Jp = b.Xt.pad0;
       ContractPlan pl = make_plan(1, 0, Jp, Jp, I, R, prec);
       b.T.ensure(pl.t_bytes()); b.frag.ensure(pl.frag_bytes(prec));
       timed_contract(b.Xt.data.p, prec, pl, F0, facs[0].ld, b.frag.p, b.T.p);
-      launch_t_to_colmajor(b.T.p, pl.tprec, pl.nchunk, pl.trows(), J, R, scale, out_local, ldOut, stream_);
+      launch_t_to_colmajor(b.T.p, pl.tprec, pl.nchunk, pl.trows(), J, R, scale, out_local, ld_local, stream_);
     }
     b.cached_mode = -1;
   } else if (b.nd == 3) {
@@ -1274,33 +1315,35 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
       if (m == 2 && ksh) return facs[2].pT + b.xp_k0 * R;
       return facs[m].pT + ((m == 0 && sharded) ? b.row0 * R : 0);
     };
-    if (ksh && pos == 2) {                             // own rows of a zeroed buffer; the all-reduce is the all-gather
-      for (int r = 0; r < R; ++r)
-        AO_HIP(hipMemsetAsync(out + ldOut * r, 0, (size_t)K * sizeof(double), stream_));
-      out_local = out + b.xp_k0;
-    }
+    if (ksh && pos == 2) own_rows_buffer(1, K, b.xp_k0);   // own rows of the zeroed send buffer; the all-reduce is the all-gather
     // the reduction over T is timed like the passes (kernel_stats slot 2): it reads all of T once
     KernelStats& rs = kstats_[2];
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (profile_ && profile_reductions_ && rs.pending.size() < 100000) {
-      e0 = take_event();
-      e1 = take_event();
-      AO_HIP(hipEventRecord(e0, stream_));
+    if (profile_ && profile_reductions_) {
+      if (rs.pending.size() >= 512) fold_finished(rs);
+      if (rs.pending.size() < 4096) {
+        e0 = take_event();
+        e1 = take_event();
+        AO_HIP(hipEventRecord(e0, stream_));
+      }
     }
     if (pos == ia) {
       b.scratch.ensure(reduce_outer_scratch_bytes(An, Bn, R));
       b.ft.ensure(reduce_factor_scratch_bytes(Bn, R));
-      launch_reduce_outer(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, fac_p(ib), facs[ib].ld, scale,
-                          out_local, ldOut, b.scratch.d(), b.ft.d(), stream_, fac_pT(ib));
+      const bool rode = launch_reduce_outer(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, fac_p(ib), facs[ib].ld, scale,
+                                            out_local, ld_local, b.scratch.d(), b.ft.d(), stream_, fac_pT(ib), 0, sys);
+      if (sys_done) *sys_done = rode;
     } else {
       AO_REQUIRE(pos == ib, "internal: cached contraction cannot serve this mode");
       b.ft.ensure(reduce_factor_scratch_bytes(An, R));
-      launch_reduce_inner(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, fac_p(ia), facs[ia].ld, scale, out_local,
-                          ldOut, b.ft.d(), stream_, fac_pT(ia));
+      const bool rode = launch_reduce_inner(b.T.p, pl.tprec, pl.nchunk, pl.trows(), An, Apad, Bn, R, fac_p(ia), facs[ia].ld, scale,
+                                            out_local, ld_local, b.ft.d(), stream_, fac_pT(ia), 0, sys);
+      if (sys_done) *sys_done = rode;
     }
     if (e0) {
       AO_HIP(hipEventRecord(e1, stream_));
       rs.pending.emplace_back(e0, e1);
+      rs.timed++;
     }
     rs.launches++;
     rs.bytes += (double)pl.t_bytes();
@@ -1343,7 +1386,7 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
       b.scratch.ensure(reduce_outer_scratch_bytes(An, b.dims[mb], R));
       b.ft.ensure(reduce_factor_scratch_bytes(b.dims[mb], R));
       launch_reduce_outer(Tin, tprec, nchunk, trows, An, Arows, b.dims[mb], R, facs[mb].p, facs[mb].ld,
-                          last ? scale : 1.0, dst, last ? ldOut : 0, b.scratch.d(), b.ft.d(), stream_, nullptr, last ? 0 : 1);
+                          last ? scale : 1.0, dst, last ? ld_local : 0, b.scratch.d(), b.ft.d(), stream_, nullptr, last ? 0 : 1);
       if (last) { nrem = 1; break; }
       Tin = dst; tprec = AOADMM_PREC_F64; nchunk = 1; trows = Arows;
       --nrem;
@@ -1358,7 +1401,7 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
       const int64_t An = ma == 0 ? I : b.dims[ma];
       b.ft.ensure(reduce_factor_scratch_bytes(An, R));
       launch_reduce_inner(Tin, tprec, nchunk, trows, An, ext[0], Brows, R, ma == 0 ? F0 : facs[ma].p, facs[ma].ld,
-                          last ? scale : 1.0, dst, last ? ldOut : 0, b.ft.d(), stream_, nullptr, last ? 0 : 1);
+                          last ? scale : 1.0, dst, last ? ld_local : 0, b.ft.d(), stream_, nullptr, last ? 0 : 1);
       Tin = dst; tprec = AOADMM_PREC_F64; nchunk = 1; trows = Brows;
       for (int q = 0; q + 1 < nrem; ++q) { rem[q] = rem[q + 1]; ext[q] = ext[q + 1]; }
       --nrem;
@@ -1366,7 +1409,10 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
     b.cached_mode = -1;
   }
   if (sharded) {
-    if (ldOut == out_rows_full) allreduce(out, out_rows_full * R);
+    if (send) {                                        // from the block's own-rows send buffer (ld = rows) into `out`
+      if (ldOut == out_rows_full) allreduce_from(send, out, out_rows_full * R);
+      else for (int r = 0; r < R; ++r) allreduce_from(send + out_rows_full * r, out + ldOut * r, out_rows_full);
+    } else if (ldOut == out_rows_full) allreduce(out, out_rows_full * R);
     else for (int r = 0; r < R; ++r) allreduce(out + ldOut * r, out_rows_full);
   }
 }
@@ -1419,7 +1465,6 @@ void Engine::prepare_mode_system(int m, int nrho, const aoadmm_options& opt) {
     facs[i] = factor_ref(o);
   }
   std::vector<int> seq = update_sequence(mi.tensor);
-  block_mttkrp(t.blk, mi.pos, facs, mi.R, t.weight, mi.A.d(), mi.rows, opt.use_dimtree != 0, seq.data(), (int)seq.size());
   SysBuild sb;
   sb.ngram = 0;
   for (int i = 0; i < t.nmodes; ++i)
@@ -1436,7 +1481,13 @@ void Engine::prepare_mode_system(int m, int nrho, const aoadmm_options& opt) {
   sb.ctl = ctl_of_mode(m);
   const int cty = mi.coupling >= 0 ? couplings_[mi.coupling].type : -1;
   if (cty == 2) sb.Madd = mi.HHt.d();
-  sys_build(sb, stream_);
+  // The system needs the Gram matrices only: it rides in the launch of the reduction that finishes the MTTKRP (one
+  // extra workgroup) when that path is taken, else it gets its own launch behind the MTTKRP.
+  static const bool no_rider = getenv("AOADMM_NO_SYS_RIDER") != nullptr;       // development switch
+  bool rode = false;
+  block_mttkrp(t.blk, mi.pos, facs, mi.R, t.weight, mi.A.d(), mi.rows, opt.use_dimtree != 0, seq.data(), (int)seq.size(), true,
+               false, no_rider ? nullptr : &sb, &rode);
+  if (!rode) sys_build(sb, stream_);
   if (cty == 1 || cty == 5) {                       // B = V diag(mu) V' for the Sylvester solve of the inner loop
     mi.eV.ensure((size_t)mi.R * mi.R * sizeof(double)); mi.eMu.ensure((size_t)mi.R * sizeof(double));
     sym_eig_small(mi.Bsys.d(), mi.R, mi.eMu.d(), mi.eV.d(), stream_);
@@ -3107,6 +3158,7 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   int iter = 1;
   bool stop = false;
   while (iter <= opt.MaxOuterIters && !stop) {                                 // :87
+    for (ModeInfo& mq : modes_) mq.quad.dirty = true;   // rho moves once per outer iteration ('quadratic regularization', non-symmetric L)
     for (int cid = -1; cid < n_couplings_; ++cid) {                            // :89 (0 = uncoupled first)
       std::vector<int> cm;
       for (int m = 0; m < n_modes_; ++m)
@@ -3208,6 +3260,53 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   out->OuterIterations = iter - 1;
   out->exit_code = iter > opt.MaxOuterIters ? 0 : 1;                           // make_exit_flag.m:4-5
   for (int i = 0; i < 4; ++i) out->exit_abs[i] = f[i] < opt.AbsFuncTol ? 1 : 0;
+}
+
+// Y = X_(n) X_(n)' of the RESIDENT data of tensor p (cmtf_nvecs.m:31-56, init_coupled_AOADMM_CMTF.m:50-73): the Gram
+// matrix whose leading eigenvectors initialise mode `pos` with init_options.nvecs = 1, without another transfer of the
+// tensor.  CP blocks (matrices, 3-way): any mode; PARAFAC2 blocks: pos 0 = [X_1 ... X_K] X_k' summed, pos 1 = X_k' X_k
+// of slab `slab`.  With a communicator the first mode of a row-sharded block has no local answer (its Gram matrix pairs
+// rows of different ranks): AOADMM_ERR_UNSUPPORTED, the caller takes aoadmm_op_unfold_gram with the host array.
+void Engine::resident_unfold_gram(int p, int pos, int slab, double* out_host) {
+  require_usable();
+  AO_REQUIRE(model_done_, "call aoadmm_model_end first");
+  AO_REQUIRE(p >= 0 && p < n_tensors_, "tensor %d out of range", p);     // out_host may be null: ranks > 0 of a multi-device context
+  AO_HIP(hipSetDevice(device_));
+  TensorInfo& t = tensors_[p];
+  UnfoldGramArgs a;
+  int prec = AOADMM_PREC_F64;
+  bool reduce = false;
+  if (t.par2) {
+    const Par2Block& b = t.p2;
+    AO_REQUIRE(pos == 0 || pos == 1, "PARAFAC2 block: mode 1 (all slabs) or mode 2 (one slab)");
+    for (int k = 0; k < b.K; ++k) AO_REQUIRE(b.have_slab[k], "slab %d of tensor %d has no data", k, p);
+    if (pos == 0) { a.X = b.X.p; a.n = b.I; a.sa = 1; a.n1 = b.Jtot; a.s1 = b.I; a.n2 = 1; a.s2 = 0; }
+    else {
+      AO_REQUIRE(slab >= 0 && slab < b.K, "slab %d out of range", slab);
+      const int64_t Jk = b.off_h[slab + 1] - b.off_h[slab];
+      a.X = b.X.d() + (int64_t)b.I * b.off_h[slab]; a.n = Jk; a.sa = b.I; a.n1 = b.I; a.s1 = 1; a.n2 = 1; a.s2 = 0;
+    }
+  } else {
+    const CpBlock& b = t.blk;
+    AO_REQUIRE(b.has_data, "tensor %d has no data", p);
+    AO_REQUIRE((b.nd == 2 || b.nd == 3) && pos >= 0 && pos < b.nd, "unfold_gram handles matrices and 3-way tensors");
+    if (sharded() && pos == 0)
+      throw Error(AOADMM_ERR_UNSUPPORTED, "resident unfold_gram: the first mode of a row-sharded block pairs rows of different ranks");
+    const int64_t I = b.dims[0], Ip = b.X.pad0, J = b.dims[1], K = b.nd == 3 ? b.dims[2] : 1;
+    prec = b.X.prec;
+    a.X = b.X.data.p;
+    if (pos == 0) { a.n = I; a.sa = 1; a.n1 = J * K; a.s1 = Ip; a.n2 = 1; a.s2 = 0; }
+    else if (pos == 1) { a.n = J; a.sa = Ip; a.n1 = I; a.s1 = 1; a.n2 = K; a.s2 = Ip * J; }
+    else { a.n = K; a.sa = Ip * J; a.n1 = Ip * J; a.s1 = 1; a.n2 = 1; a.s2 = 0; }   // padding rows are zeros
+    reduce = sharded();                                 // partial sums over this rank's rows
+  }
+  DevBuf ws, y;
+  ws.alloc(unfold_gram_ws_bytes(a));
+  y.alloc((size_t)a.n * a.n * sizeof(double));
+  unfold_gram(a, prec, ws.d(), y.d(), stream_);
+  if (reduce) allreduce(y.d(), a.n * a.n);
+  if (out_host) AO_HIP(hipMemcpyAsync(out_host, y.p, (size_t)a.n * a.n * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  AO_HIP(hipStreamSynchronize(stream_));
 }
 
 void Engine::resident_mttkrp(int p, int pos, double* out_host, float* ms) {

@@ -90,8 +90,22 @@ def cmtf_nvecs(Z, n, r, engine=None):
     which_p = _which_p(Z)
     p = which_p[n]
     md = [m - 1 for m in Z['modes'][p]]
-    Y = eng.unfold_gram(np.asarray(Z['object'][p], dtype=np.float64), md.index(n))
+    Y = _resident_gram(eng, Z, p, md.index(n), int(Z['size'][n]))
+    if Y is None:
+        Y = eng.unfold_gram(np.asarray(Z['object'][p], dtype=np.float64), md.index(n))
     return _leading_eigvecs(Y, r)
+
+
+def _resident_gram(eng, Z, p, pos, n, slab=0):
+    """Gram matrix of an unfolding from the data `build_model(eng, Z)` already put on the device (cmtf_nvecs.m unfolds the
+    array it already holds: no second transfer of the tensor); None when this Z is not the engine's resident model or
+    the engine cannot answer locally (first mode of a row-sharded block)."""
+    if getattr(eng, '_resident_model', None) is not Z:
+        return None
+    try:
+        return eng.resident_unfold_gram(p, pos, n, slab)
+    except capi.UnsupportedOnDevice:
+        return None
 
 
 def init_coupled_AOADMM_CMTF(Z, init_options, Delta=None, rng=None, engine=None):
@@ -126,16 +140,21 @@ def init_coupled_AOADMM_CMTF(Z, init_options, Delta=None, rng=None, engine=None)
                 if Z['model'][p] == 'CP':
                     A['fac'][n] = cmtf_nvecs(Z, n, R, eng_nv)
                 elif md.index(n) == 0:
-                    M = np.hstack([np.asarray(Xk, dtype=np.float64) for Xk in Z['object'][p]])
-                    A['fac'][n] = _leading_eigvecs(eng_nv.unfold_gram(M, 0), R)
+                    Y = _resident_gram(eng_nv, Z, p, 0, int(sz[n]))
+                    if Y is None:
+                        M = np.hstack([np.asarray(Xk, dtype=np.float64) for Xk in Z['object'][p]])
+                        Y = eng_nv.unfold_gram(M, 0)
+                    A['fac'][n] = _leading_eigvecs(Y, R)
                 elif md.index(n) == 1:
                     A['DeltaB'][p] = rng.random((R, R))
                     A['fac'][n] = []
                     A['P'][p] = []
                     A['mu_DeltaB'][p] = []
                     for k in range(len(sz[n])):
-                        Xk = np.asarray(Z['object'][p][k], dtype=np.float64)
-                        A['fac'][n].append(_leading_eigvecs(eng_nv.unfold_gram(Xk, 1), R))
+                        Y = _resident_gram(eng_nv, Z, p, 1, int(sz[n][k]), k)
+                        if Y is None:
+                            Y = eng_nv.unfold_gram(np.asarray(Z['object'][p][k], dtype=np.float64), 1)
+                        A['fac'][n].append(_leading_eigvecs(Y, R))
                         A['P'][p].append(np.eye(sz[n][k], R))
                         A['mu_DeltaB'][p].append(rng.random((sz[n][k], R)))
                 else:
@@ -244,6 +263,7 @@ def build_model(eng, Z, precision='f64'):
             raise capi.UnsupportedOnDevice(capi.ERR_UNSUPPORTED,
                                            "loss '%s' needs the L-BFGS-B path of the MATLAB code" % Z['loss_function'][p])
     miss = Z.get('miss') if Z.get('miss') is not None else [None] * P
+    eng._resident_model = None
     capi.check(lib.aoadmm_model_begin(eng.h, nb_modes, P, nb_couplings))
     R_of = {}
     for p in range(P):
@@ -329,6 +349,7 @@ def build_model(eng, Z, precision='f64'):
                         raise ValueError('Z.miss{%d}{%d} size does not match Z.object{%d}{%d}.' % (p + 1, k + 1, p + 1, k + 1))
                     mk = np.asfortranarray(mk != 0, dtype=np.uint8)
                     capi.check(lib.aoadmm_par2_slab_mask_upload(eng.h, p, k, mk.ctypes.data_as(C.POINTER(C.c_uint8))))
+    eng._resident_model = Z            # init_coupled_AOADMM_CMTF(nvecs = 1) on this Z takes its Gram matrices from here
 
 
 def _put_cells(eng, field, index, cells):

@@ -131,6 +131,12 @@ class Engine:
         capi.check(self.lib.aoadmm_op_unfold_gram(self.h, capi.dptr(X), X.ndim, dims, int(n), prec, capi.dptr(out)))
         return out
 
+    def resident_unfold_gram(self, p, tensor_mode, n, slab=0):
+        """The same Gram matrix (n x n) from the data of tensor p already on the device (`aoadmm_resident_unfold_gram`)."""
+        out = np.zeros((n, n), order='F')
+        capi.check(self.lib.aoadmm_resident_unfold_gram(self.h, int(p), int(tensor_mode), int(slab), capi.dptr(out)))
+        return out
+
     def gram(self, F):
         F = capi.as_f(F)
         out = np.zeros((F.shape[1], F.shape[1]), order='F')

@@ -271,6 +271,66 @@ def test_nvecs_initialisation(pkg, eng):
             assert same_span(fo, fg), m
 
 
+def test_nvecs_initialisation_from_resident_data(pkg):
+    """The same initialisation when the model is built first: the Gram matrices come from the data already on the device
+    (`aoadmm_resident_unfold_gram`; cmtf_nvecs.m:31-56 unfolds the array it already holds) and agree with the
+    host-array form to 1e-12; the factors span the oracle's subspaces.  Also a synthetic (device-generated) block, which
+    has no host array at all."""
+    from oracle import aoadmm as OA
+    from helpers import script1_model
+    rng = np.random.default_rng(71)
+    Z, io = script1_model(rng, dims=(20, 30, 40), K=6, Jk=30, noise=0.05)
+    io = dict(io, nvecs=1)
+    Go = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(3))
+    with pkg.Engine(0) as e:
+        Z['_ranks'] = [3] * 6
+        pkg.build_model(e, Z, 'f64')
+        assert e._resident_model is Z
+        # every Gram matrix both ways
+        X1 = np.asarray(Z['object'][0])
+        for n in range(3):
+            a = e.resident_unfold_gram(0, n, X1.shape[n])
+            b = e.unfold_gram(X1, n)
+            assert np.linalg.norm(a - b) <= 1e-12 * np.linalg.norm(b), n
+        M = np.hstack(Z['object'][1])
+        a = e.resident_unfold_gram(1, 0, M.shape[0])
+        assert np.linalg.norm(a - M @ M.T) <= 1e-12 * np.linalg.norm(M @ M.T)
+        for k, Xk in enumerate(Z['object'][1]):
+            a = e.resident_unfold_gram(1, 1, Xk.shape[1], k)
+            assert np.linalg.norm(a - Xk.T @ Xk) <= 1e-12 * np.linalg.norm(Xk.T @ Xk), k
+        calls = []
+        orig = e.unfold_gram
+        e.unfold_gram = lambda *a_, **k_: (calls.append(1), orig(*a_, **k_))[1]
+        Gg = pkg.init_coupled_AOADMM_CMTF(Z, io, rng=np.random.default_rng(3), engine=e)
+        assert not calls                                 # nothing went through the host-array form
+
+    def same_span(a, b):
+        return np.linalg.norm(a @ (a.T @ b) - b) < 1e-8 * np.linalg.norm(b)
+    for m, (fo, fg) in enumerate(zip(Go['fac'], Gg['fac'])):
+        if isinstance(fo, list):
+            assert all(same_span(x, y) for x, y in zip(fo, fg))
+        elif np.allclose(fo, 1.0):
+            assert np.allclose(fg, 1.0)
+        else:
+            assert same_span(fo, fg), m
+    # a block generated in HBM: nvecs = 1 works without any host copy of the tensor
+    n, R = 48, 4
+    Zs = dict(loss_function=['Frobenius'], model=['CP'], modes=[[1, 2, 3]], size=[n, n + 4, n + 8],
+              coupling=dict(lin_coupled_modes=[0, 0, 0], coupling_type=[], coupl_trafo_matrices=[None] * 3),
+              constrained_modes=[0, 0, 0], constraints=[None] * 3, weights=[1.0],
+              object=[dict(synthetic=True, rank=R, seed=5, noise=0.0)], _ranks=[R] * 3)
+    with pkg.Engine(0) as e:
+        pkg.build_model(e, Zs, 'f64')
+        io2 = dict(lambdas_init=[[1] * R], nvecs=1, distr=[lambda a, b: np.zeros((a, b))] * 3, normalize=0)
+        Gs = pkg.init_coupled_AOADMM_CMTF(Zs, io2, rng=np.random.default_rng(1), engine=e)
+        for m, f in enumerate(Gs['fac']):
+            assert f.shape == (Zs['size'][m], R) and np.allclose(f.T @ f, np.eye(R), atol=1e-10)
+        # noise-free rank-R data: the leading eigenvectors span the generating factor, so R eigenvalues carry everything
+        Y = e.resident_unfold_gram(0, 0, n)
+        w = np.sort(np.linalg.eigvalsh(Y))[::-1]
+        assert w[R] < 1e-10 * w[0]
+
+
 @pytest.mark.parametrize('dims', [(9, 7, 6, 5), (13, 4, 6, 3, 5), (34, 3, 2, 17)])
 @pytest.mark.parametrize('prec,tol', [('f64', 1e-12), ('f32', 3e-6)])
 def test_mttkrp_nway(pkg, eng, dims, prec, tol):

@@ -157,6 +157,18 @@ def test_slab_sharded_irregular_parafac2(pkg, world):
     compare_par2(*run_sharded_par2(pkg, Z, io, options(MaxOuterIters=10), world))
 
 
+def test_config4_as_written_256_slabs_over_4_ranks(pkg):
+    """BASELINE config 4 as written: irregular PARAFAC2 (example_script4 shapes: I = 40, R = 3, J_k cycled over 61..120,
+    C non-negative), K = 256 slabs sharded over 4 ranks (64 slabs each) with par2_slab_sharding = 1; the collectives go
+    through the process-local group (host-staged sums: RCCL refuses four ranks on one device).  Every field of G within
+    1e-8 of the oracle, all ranks bit-identical.  Sums over k: cmtf_fun_AOADMM.m:163-164 (mode A), :537-547 (DeltaB
+    per inner iteration), :582-585 (residual means)."""
+    from helpers import script4_model
+    rng = np.random.default_rng(21)
+    Z, io = script4_model(rng, K=256)
+    compare_par2(*run_sharded_par2(pkg, Z, io, options(MaxOuterIters=5), 4))
+
+
 def test_slab_sharded_constrained_and_regularised_Bk(pkg):
     from helpers import script4_model
     rng = np.random.default_rng(11)

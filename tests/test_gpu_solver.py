@@ -69,8 +69,8 @@ def test_cp_tv_long_mode(pkg, eng):
 
 def test_cp_quadratic_nonsymmetric(pkg, eng):
     """{'quadratic regularization', eta, L} with a NON-symmetric L (constraints_to_prox.m:62-67 solves
-    (2 eta/rho L + I) \\ x for any L): no eigenbasis, the library inverts the matrix on the host whenever rho has moved
-    and the device prox is one GEMM.  Solver parity at 1e-8, op-level at 1e-11, and a symmetric L right after it on the
+    (2 eta/rho L + I) \\ x for any L): no eigenbasis, the library inverts the matrix on the device (Gauss-Jordan with row
+    pivoting, rho read from device memory: no host round trip) once per outer iteration and the prox is one GEMM.  Solver parity at 1e-8, op-level at 1e-11, and a symmetric L right after it on the
     same engine (the two preparations must not leak into each other)."""
     rng = np.random.default_rng(52)
     n = 41
@@ -90,6 +90,19 @@ def test_cp_quadratic_nonsymmetric(pkg, eng):
     P = np.roll(np.eye(n), 1, axis=0) * 50.0 - np.eye(n) * (0.7 / (2.0 * 0.05))     # 2 eta/rho L + I has a zero diagonal
     got = eng.prox(('quadratic regularization', 0.05, P), x, 0.7)
     assert rel_fro(got, np.linalg.solve(2.0 * 0.05 / 0.7 * P + np.eye(n), x)) < 1e-11
+
+
+def test_quadratic_nonsymmetric_larger_matrix(eng):
+    """The device-side pivoted inverse beyond one workgroup's worth of rows (several row tiles, ragged column tiles):
+    n = 700 rows, non-symmetric L, against numpy's LU solve at 1e-10; a second rho reuses nothing."""
+    rng = np.random.default_rng(53)
+    n = 700
+    L = rng.standard_normal((n, n)) / np.sqrt(n) + np.diag(1.0 + rng.random(n))
+    x = rng.standard_normal((n, 6))
+    for rho in (1.3, 0.4):
+        got = eng.prox(('quadratic regularization', 0.3, L), x, rho)
+        ref = np.linalg.solve(2.0 * 0.3 / rho * L + np.eye(n), x)
+        assert rel_fro(got, ref) < 1e-10, rel_fro(got, ref)
 
 
 def test_cp_mixed_constraints_and_ls(pkg, eng):
