@@ -293,11 +293,10 @@ __global__ __launch_bounds__(kSpecThreads) void admm_rows_mfma_k(FusedArgs a, Sp
     int ks = a.max_inner;
     bool found = false;
 #pragma unroll
-    for (int it = 1; it <= kSpecMaxInner; ++it) {
-      if (it > a.max_inner) break;                     // uniform: iterations beyond the cap need no sums
+    for (int it = 1; it <= kSpecMaxInner; ++it) {    // (no early break: with one the array S went to scratch memory)
       double s0 = S[it - 1][0], s1 = S[it - 1][1], s2 = S[it - 1][2], s3 = S[it - 1][3];
       s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);   // the same total in every lane
-      if (!found) {
+      if (!found && it <= a.max_inner) {
         pr = sqrt(s0) / sqrt(s1);                                            // :1085
         const double sc = sqrt(s2);
         du = sc > 0 ? sqrt(s3) / sc : sqrt(s3);                              // :1087-1092
@@ -415,6 +414,11 @@ __global__ __launch_bounds__(kSpecThreads) void admm_rows_mfma_k(FusedArgs a, Sp
     }
 }
 
+// (A one-launch form of this loop -- the workgroups meeting at a grid barrier instead of a kernel boundary, the result of
+// pass 1 kept in registers when the loop ran to its cap -- was built and measured in round 3: 735 GPU tests green, but no
+// faster: 1.279 against 1.274 ms per iteration at one rank's share of 8 GPUs, 7.92 against 7.94 ms at one GPU.  The
+// workgroups sit on eight dies with separate L2s; an agent-scope barrier (release fence = L2 write-back, atomics and
+// acquire loads that go past the L2) costs about what the kernel boundary costs, ~10 us.  Not kept.)
 // Thread-per-row variant for the triangular-solve path (no explicit inverse available: op-level entry)
 template <int RMAX>
 __global__ __launch_bounds__(kRowThreads) void admm_rowL_k(FusedArgs a) {

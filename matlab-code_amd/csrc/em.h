@@ -11,7 +11,7 @@ namespace aoadmm {
 
 struct EmCpArgs {
   void* X;                 // float / double, first dimension padded to `Ipad`
-  const uint8_t* mask;     // same layout, 1 = observed
+  const uint8_t* mask;     // ONE BIT per entry of the same layout (em_mask_pack), 1 = observed
   const double *A, *B, *C; // factors, column-major; A points at the block's first local row; C null for matrices
   int64_t ldA, ldB, ldC;
   int64_t I, Ipad, J, K;   // local rows, padded rows, second mode, third mode (1 for matrices)
@@ -26,6 +26,10 @@ struct EmCpArgs {
   void* T = nullptr;
   int64_t t_chunk_stride = 0;
 };
+// bits[e >> 3] bit (e & 7) = bytes[e] != 0 for e < n; room for cdiv(n, 8) + 16 bytes (the strip kernel's clamped
+// look-ahead loads stay inside the block, the slack is for the padding of the last byte)
+void em_mask_pack(const uint8_t* bytes, uint8_t* bits, int64_t n, hipStream_t s);
+inline size_t em_mask_bits_bytes(int64_t n) { return (size_t)((n + 7) / 8 + 16); }
 constexpr int kEmFuseMaxRank = 24;
 bool em_cp_can_fuse(const EmCpArgs& a, int prec);
 int em_cp_fused_chunks(const EmCpArgs& a, int prec);

@@ -5,8 +5,9 @@
 // CP block: one workgroup owns a strip of 256*VEC first-mode rows at one third-mode index k and walks the
 // second mode.  A thread keeps its VEC rows of A, pre-multiplied by C(k,:), in registers; rows of B are
 // staged through LDS 64 at a time and broadcast.  The model value is VEC*R FMAs per vector of entries, the
-// tensor is read once (16-byte loads) and only vectors that contain a missing entry are written back:
-// the pass is bound by HBM like the contractions.
+// tensor is read once (16-byte loads), the mask is ONE BIT per entry (packed on the device when Z.miss arrives: at
+// 1000^3 the byte-per-entry mask was 1 GB of the pass's 9 GB), and only 128-byte lines that contain a missing entry are
+// written back: the pass is bound by HBM like the contractions.
 #include "em.h"
 
 #include <type_traits>
@@ -14,8 +15,30 @@
 namespace aoadmm {
 
 template <typename T, int VEC> struct EmVec;
-template <> struct EmVec<float, 4> { typedef float type __attribute__((ext_vector_type(4))); typedef uint32_t mtype; };
-template <> struct EmVec<double, 2> { typedef double type __attribute__((ext_vector_type(2))); typedef uint16_t mtype; };
+template <> struct EmVec<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct EmVec<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+
+// Z.miss as one bit per entry (bit e of the padded layout in byte e >> 3, position e & 7), 1 = observed.  A thread's VEC
+// entries start at a multiple of VEC, so they sit in one byte.
+__global__ void em_mask_pack_k(const uint8_t* __restrict__ bytes, uint8_t* __restrict__ bits, int64_t n) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // output byte
+  const int64_t e0 = o * 8;
+  if (e0 >= n) return;
+  unsigned v = 0;
+  if (e0 + 8 <= n) {
+    const uint64_t w = *reinterpret_cast<const uint64_t*>(bytes + e0);     // cudaMalloc-aligned base, e0 multiple of 8
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v |= (((w >> (8 * q)) & 0xff) != 0 ? 1u : 0u) << q;
+  } else {
+    for (int q = 0; q < 8; ++q) v |= ((e0 + q < n ? bytes[e0 + q] : 1) != 0 ? 1u : 0u) << q;   // past the end: observed
+  }
+  bits[o] = (uint8_t)v;
+}
+void em_mask_pack(const uint8_t* bytes, uint8_t* bits, int64_t n, hipStream_t s) {
+  const int64_t nb = cdiv(n, (int64_t)8);
+  em_mask_pack_k<<<(unsigned)cdiv(nb, (int64_t)256), 256, 0, s>>>(bytes, bits, n);
+  AO_KERNEL_CHECK();
+}
 
 static constexpr int kEmThreads = 256;
 static constexpr int kEmJTile = 64;
@@ -104,8 +127,9 @@ __device__ __forceinline__ void em_row_axpy(XV* tacc, const T* brow, XV x) {
 //     lane) and join the fp64 sums once per tile
 //   * padding rows (i >= I; the tensor holds zeros there) get a zero row of A and are forced 'observed': they add
 //     exact zeros and are written back unchanged
-//   * every vector is written back with a streaming store, not only those with a missing entry: whole cache lines
-//     leave and nothing is read-modified-written in L2
+//   * write-back by 128-byte line: a line leaves (streaming stores of all its vectors) when any of its entries is
+//     missing -- whole cache lines, nothing read-modified-written in L2 (storing only the VECTORS with a missing entry
+//     measured slower than storing everything); at 20 % missing every line qualifies, at 1 % about a quarter
 //   * the strip can walk the second mode at a fixed third-mode index (walk = 1) or the third mode at a fixed
 //     second-mode index (walk = 2, steps of Ipad*J elements); with FUSE it also accumulates, from the values it
 //     writes back, the partial contraction of the walked mode  T(i, f, r) = sum_w x_new(i, w, f) W(w, r)  -- the
@@ -114,7 +138,8 @@ __device__ __forceinline__ void em_row_axpy(XV* tacc, const T* brow, XV x) {
 template <typename T, int VEC, int RMAX, bool FUSE>
 __global__ __launch_bounds__(kEmThreads, FUSE ? 2 : 1) void em_cp_vec_k(EmCpArgs a, int jchunks, int64_t jlen, double* ws) {
   typedef typename EmVec<T, VEC>::type XV;
-  typedef typename EmVec<T, VEC>::mtype MV;
+  typedef uint8_t MV;                                                    // the byte that holds this thread's VEC mask bits
+  constexpr unsigned kFull = (1u << VEC) - 1u;
   __shared__ __attribute__((aligned(16))) T Bsh[kEmJTile][RMAX];
   __shared__ double sh4[4];
   const int R = a.R;
@@ -131,10 +156,10 @@ __global__ __launch_bounds__(kEmThreads, FUSE ? 2 : 1) void em_cp_vec_k(EmCpArgs
   const int64_t i0 = ((int64_t)(blockIdx.x / jchunks) * kEmThreads + t) * VEC;   // first row of this thread
   const int64_t jbeg = chunk * jlen, jend = jbeg + jlen < NW ? jbeg + jlen : NW;
   XV areg[RMAX];                                                         // areg[r][v] = A(i0+v, r) * Ff(f, r)
-  MV padmask = 0;
+  unsigned padmask = 0;
 #pragma unroll
   for (int v = 0; v < VEC; ++v)
-    if (i0 + v >= a.I) padmask |= (MV)((MV)0xff << (8 * v));
+    if (i0 + v >= a.I) padmask |= 1u << v;
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) {
     const int rr = r < R ? r : 0;
@@ -150,7 +175,10 @@ __global__ __launch_bounds__(kEmThreads, FUSE ? 2 : 1) void em_cp_vec_k(EmCpArgs
   }
   const int64_t base = (wj ? a.Ipad * a.J : a.Ipad) * f;
   T* X = reinterpret_cast<T*>(a.X) + base;
-  const uint8_t* M = a.mask + base;
+  const uint8_t* M = a.mask;                                             // bits: entry e at byte e >> 3, position e & 7
+  const int64_t mbase = base + i0;                                       // this thread's first entry at walk position 0
+  const unsigned sh0 = (unsigned)(mbase & 7), shs = (unsigned)(step & 7);   // position inside the byte at walk position w: (sh0 + shs*w) & 7
+  const int lane = t & 63;
   const bool in_range = i0 < a.Ipad;                                     // Ipad is a multiple of VEC
   const XV zero = {};
   XV tacc[FUSE ? RMAX : 1];
@@ -170,9 +198,10 @@ __global__ __launch_bounds__(kEmThreads, FUSE ? 2 : 1) void em_cp_vec_k(EmCpArgs
     XV xq[PD]; MV mq[PD];
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
-      const int64_t op = i0 + step * (j0 + (p < nj ? p : nj - 1));
+      const int64_t wp = j0 + (p < nj ? p : nj - 1);
+      const int64_t op = i0 + step * wp;
       xq[p] = __builtin_nontemporal_load(reinterpret_cast<const XV*>(X + op));
-      mq[p] = __builtin_nontemporal_load(reinterpret_cast<const MV*>(M + op));
+      mq[p] = M[(mbase + step * wp) >> 3];
     }
     XV s_ores = zero, s_ox2 = zero, s_num = zero, s_den = zero;
     for (int jj = 0; jj < nj; jj += PD) {
@@ -180,12 +209,12 @@ __global__ __launch_bounds__(kEmThreads, FUSE ? 2 : 1) void em_cp_vec_k(EmCpArgs
       for (int p = 0; p < PD; ++p) {
         const int jc = jj + p;                                           // wave-uniform
         const XV xv = xq[p];
-        const MV mv = mq[p] | padmask;
+        const unsigned mv = (((unsigned)mq[p] >> ((sh0 + shs * (unsigned)(j0 + jc)) & 7u)) & kFull) | padmask;
         {
           const int jn = jc + PD < nj ? jc + PD : nj - 1;                // clamped: the last loads are discarded
           const int64_t on = i0 + step * (j0 + jn);
           xq[p] = __builtin_nontemporal_load(reinterpret_cast<const XV*>(X + on));
-          mq[p] = __builtin_nontemporal_load(reinterpret_cast<const MV*>(M + on));
+          mq[p] = M[(mbase + step * (j0 + jn)) >> 3];
         }
         if (jc < nj) {
           const XV m = em_row_dot<T, VEC, RMAX, XV>(areg, &Bsh[jc][0], zero);
@@ -193,7 +222,7 @@ __global__ __launch_bounds__(kEmThreads, FUSE ? 2 : 1) void em_cp_vec_k(EmCpArgs
           XV od, ox, xn;                                                 // residual / value where observed, else 0
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            const bool observed = ((mv >> (8 * v)) & 0xff) != 0;
+            const bool observed = ((mv >> v) & 1u) != 0;
             od[v] = observed ? d[v] : (T)0;
             ox[v] = observed ? xv[v] : (T)0;
             xn[v] = observed ? xv[v] : m[v];
@@ -203,7 +232,19 @@ __global__ __launch_bounds__(kEmThreads, FUSE ? 2 : 1) void em_cp_vec_k(EmCpArgs
           s_ox2 = __builtin_elementwise_fma(ox, ox, s_ox2);
           s_num = __builtin_elementwise_fma(md, md, s_num);
           s_den = __builtin_elementwise_fma(mx, mx, s_den);
-          if (a.update) __builtin_nontemporal_store(xn, reinterpret_cast<XV*>(X + i0 + step * (j0 + jc)));
+          if (a.update) {
+            // Only 128-byte lines with a missing entry go back (at 1-5 % missing most lines hold none; whole lines, so
+            // nothing is read-modified-written in L2 -- storing single 16-byte vectors was slower than storing everything).
+            // The wave's 1024 bytes start 16-byte aligned: lane l shares its line with the lanes of the same (l + s) >> 3,
+            // s = the first lane's 16-byte slot inside its line; lines cut by the wave's ends go back if this wave's part
+            // of them has a missing entry.
+            XV* dst = reinterpret_cast<XV*>(X + i0 + step * (j0 + jc));
+            const unsigned long long bal = __ballot(mv != kFull);
+            const unsigned s16 = (unsigned)(((reinterpret_cast<uintptr_t>(dst) >> 4) - (unsigned)lane) & 7u);
+            const unsigned g = ((unsigned)lane + s16) >> 3;
+            const unsigned grp = g < 8 ? (unsigned)((bal << s16) >> (8 * g)) & 0xffu : (unsigned)(bal >> (64 - s16)) & 0xffu;
+            if (grp) __builtin_nontemporal_store(xn, dst);
+          }
           if constexpr (FUSE) em_row_axpy<T, VEC, RMAX, XV>(tacc, &Bsh[jc][0], xn);
         }
         // 2 * RMAX vectors are live across the loop: keep the scheduler from interleaving the columns of one
@@ -270,7 +311,8 @@ __global__ __launch_bounds__(kEmThreads) void em_cp_k(EmCpArgs a, int jchunks, i
     }
   }
   T* X = reinterpret_cast<T*>(a.X) + a.Ipad * a.J * k;
-  const uint8_t* M = a.mask + a.Ipad * a.J * k;
+  const uint8_t* M = a.mask;                                             // bits (see em_mask_pack_k)
+  const int64_t mb = a.Ipad * a.J * k;
   double num = 0, den = 0, ores = 0, ox2 = 0;
   for (int64_t j0 = jbeg; j0 < jend; j0 += kEmJTile) {
     __syncthreads();
@@ -288,7 +330,7 @@ __global__ __launch_bounds__(kEmThreads) void em_cp_k(EmCpArgs a, int jchunks, i
 #pragma unroll
       for (int r = 0; r < RMAX; ++r) m += areg[r] * Bsh[jj][r];
       const T d = x - m;
-      if (M[o]) {
+      if ((M[(mb + o) >> 3] >> ((mb + o) & 7)) & 1) {
         ores += (double)(d * d); ox2 += (double)(x * x);
       } else {
         num += (double)(d * d); den += (double)(x * x);

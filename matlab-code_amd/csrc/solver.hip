@@ -727,19 +727,27 @@ void Engine::tensor_mask_upload(int p, const uint8_t* mask) {
   const int64_t Iloc = b.dims[0], Ip = b.X.pad0, Ifull = b.full0;
   int64_t ncols = 1;
   for (int i = 1; i < b.nd; ++i) ncols *= b.dims[i];
-  b.mask.alloc((size_t)Ip * ncols);
-  AO_HIP(hipMemsetAsync(b.mask.p, 1, (size_t)Ip * ncols, stream_));
+  // the caller's bytes land in a staging buffer in the padded layout and are packed to one bit per entry on the device
+  // (the EM pass reads the mask once per outer iteration: 1/8 of the bytes, and 7/8 of a byte per entry of HBM back)
+  DevBuf bytes;
+  bytes.alloc((size_t)Ip * ncols);
+  AO_HIP(hipMemsetAsync(bytes.p, 1, (size_t)Ip * ncols, stream_));
   // rows [row0, row0 + Iloc) of every column of the full column-major mask; the padding rows stay 1
-  AO_HIP(hipMemcpy2DAsync(b.mask.p, (size_t)Ip, mask + b.row0, (size_t)Ifull, (size_t)Iloc, (size_t)ncols,
+  AO_HIP(hipMemcpy2DAsync(bytes.p, (size_t)Ip, mask + b.row0, (size_t)Ifull, (size_t)Iloc, (size_t)ncols,
                           hipMemcpyHostToDevice, stream_));
+  b.mask.alloc(em_mask_bits_bytes(Ip * ncols));
+  em_mask_pack(bytes.as<uint8_t>(), b.mask.as<uint8_t>(), Ip * ncols, stream_);
   if (b.nd == 2) {                                   // matrices keep a transposed copy of the data: mask too
     const int64_t J = b.dims[1], Jp = b.Xt.pad0;
     std::vector<uint8_t> mt((size_t)Jp * Iloc, 1);
     for (int64_t i = 0; i < Iloc; ++i)
       for (int64_t j = 0; j < J; ++j) mt[(size_t)j + (size_t)Jp * i] = mask[b.row0 + i + Ifull * j];
-    b.maskT.alloc(mt.size());
-    AO_HIP(hipMemcpyAsync(b.maskT.p, mt.data(), mt.size(), hipMemcpyHostToDevice, stream_));
-    AO_HIP(hipStreamSynchronize(stream_));
+    DevBuf bytesT;
+    bytesT.alloc(mt.size());
+    AO_HIP(hipMemcpyAsync(bytesT.p, mt.data(), mt.size(), hipMemcpyHostToDevice, stream_));
+    b.maskT.alloc(em_mask_bits_bytes((int64_t)mt.size()));
+    em_mask_pack(bytesT.as<uint8_t>(), b.maskT.as<uint8_t>(), (int64_t)mt.size(), stream_);
+    AO_HIP(hipStreamSynchronize(stream_));             // bytesT and mt are locals
   }
   AO_HIP(hipStreamSynchronize(stream_));
   b.has_mask = true;

@@ -485,6 +485,25 @@ def test_cp_four_way(pkg, eng):
     compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=10)))
 
 
+@pytest.mark.parametrize('dims,prec,frac', [((1100, 9, 7), 'f32', 0.01), ((1099, 9, 7), 'f64', 0.01),
+                                            ((1029, 11, 5), 'f32', 0.003), ((523, 6, 7), 'f64', 0.05),
+                                            ((2051, 13), 'f32', 0.01)])
+def test_em_sparse_missing_line_writeback(pkg, eng, dims, prec, frac):
+    """Few missing entries: the EM pass writes back only the 128-byte lines that hold one (em.hip), found with a wave
+    ballot over the one-bit-per-entry mask; several waves per strip, first modes whose padded length puts the columns
+    at every 16-byte slot of a line (1100 -> 4400 bytes per column, 1029 -> 1032 floats), fp32 and fp64 vectors.
+    The imputed entries enter every later iteration, so the factors compared after 4 iterations catch a line that was
+    not written (or a clean one that was changed)."""
+    rng = np.random.default_rng(int(1000 * frac) + dims[0])
+    Z, io, _ = cp_model(dims, 3, rng, [('non-negativity',)] + [None] * (len(dims) - 1))
+    Z = _with_mask(Z, rng, frac=frac)
+    Fo, oo, Fg, og = run_both(pkg, eng, Z, io, options(MaxOuterIters=4), precision=prec)
+    tol = 1e-4 if prec == 'f32' else 1e-8
+    for a, b in zip(Fo['fac'], Fg['fac']):
+        assert rel_fro(b, a) < tol
+    assert np.allclose(og['func_rel_missing'][1:], oo['func_rel_missing'][1:], rtol=1e-3 if prec == 'f32' else 1e-7)
+
+
 def test_parafac2_C_mode_coupling_dense_system(pkg, eng):
     """Type 1 with an H whose H'H is NOT diagonal (means of neighbouring rows): the (K*R) x (K*R) system stays dense --
     one-workgroup Cholesky + column-parallel inverse (csrc/small.hip dense_spd_inverse).  Selection matrices (script 14)
