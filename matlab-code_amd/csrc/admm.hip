@@ -784,7 +784,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
   double* dyn = GLOBAL ? a.ws + (size_t)blockIdx.x * tv_ws_doubles(a.rows) : lds_dyn;
   __shared__ int wsum[NW];
   __shared__ double dsum[NW];
-  __shared__ int flag_merge, flag_split;
+  __shared__ int flag_merge[2], flag_split[2];          // alternate by round: the reset of one never races with the read of the other
   const int n = (int)a.rows;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int r = blockIdx.x;
@@ -799,6 +799,8 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
   signed char* J = reinterpret_cast<signed char*>(start + n + 1);  // n
   const int chunk = (n + kTvThreads - 1) / kTvThreads;
   const int c0 = min(n, t * chunk), c1 = min(n, c0 + chunk);
+  constexpr int kKeep = GLOBAL ? 1 : kTvParMax / kTvThreads;      // entries per thread of an LDS-resident column (<= 4096 rows)
+  double keep_mu[kKeep], keep_z[kKeep];                            // old mu / old Z of the entries t + k*kTvThreads (fz only)
   // ---- load (coalesced, all loads of a thread independent: a chunk-ordered loop would serialise 8-16 memory
   // round trips), mean, centred prefix sums.  The warm-start column is staged in `val` the same way.
   {
@@ -806,6 +808,11 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
     // an exec-mask branch in between: written as `for (i = t; i < n; i += 256) y[i] = vin[i]` the compiler emitted one
     // s_waitcnt vmcnt(0) per element, i.e. 8-16 dependent memory round trips before the kernel could start
     const double* wv = warm ? warm + ldw * r : vin;      // no warm start: a second read of the column, discarded
+    // With `fz` the dual update at the end needs the old mu and the old Z of the same entries (t + k*kTvThreads): they
+    // are fetched here, in the kernel's first round trip, and wait in registers (fz.Z is the warm-start column) -- read
+    // at the end they were one more dependent memory round trip per call.
+    const double* mv = fz.mu ? fz.mu + fz.ld * r : vin;
+    const double* zv = fz.Z ? fz.Z + fz.ld * r : vin;    // (the same column as `wv` in the ADMM loop: the load hits the same lines)
     auto stage = [&](auto kper_tag) {
       constexpr int KP = decltype(kper_tag)::value;
       double ry[KP], rw[KP];
@@ -814,6 +821,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
         const int i = min(t + k * kTvThreads, n - 1);
         ry[k] = vin[i];
         rw[k] = wv[i];
+        if (k < kKeep) { keep_mu[k] = mv[i]; keep_z[k] = zv[i]; }
       }
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
@@ -857,18 +865,18 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
     __syncthreads();
     return base + inc - v;
   };
+  // ONE scan gives the mean and the centred prefix sums: the exclusive prefix of the plain sums at the thread's first
+  // entry, less c times the number of entries before it, is the prefix of the centred values (the difference of the two
+  // forms is a rounding of size |prefix| * 2^-53, far below the 1e-13 slack of `thr`; two scans were two more barriers)
+  const double* sol = val;                                          // where the solution ends up (val, or Pc after the expansion)
   double tot;
-  (void)block_scan_d(loc, tot);
+  const double before = block_scan_d(loc, tot);
   const double c = n > 0 ? tot / n : 0.0;
   if (!(lam > 0.0)) {
     for (int i = c0; i < c1; ++i) val[i] = y[i];
   } else {
-    double locc = 0.0;
-    for (int i = c0; i < c1; ++i) locc += y[i] - c;
-    double tot2;
-    double run = block_scan_d(locc, tot2);
+    double run = before - c * (double)c0;
     for (int i = c0; i < c1; ++i) { Pc[i] = run; run += y[i] - c; }
-    (void)tot2;
     if (c1 == n && c0 < n) Pc[n] = run;                            // the thread holding the last entry
     // ---- warm start of the jump set
     if (warm) {
@@ -890,7 +898,8 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
       int inc = cnt;
       inc = wave_scan_incl(inc);
       if (lane == 63) wsum[w] = inc;
-      if (t == 0) { flag_merge = 0; flag_split = 0; }
+      const int fp = round & 1;
+      if (t == 0) { flag_merge[fp] = 0; flag_split[fp] = 0; }
       __syncthreads();
       int base = 0;
       for (int q = 0; q < w; ++q) base += wsum[q];
@@ -917,11 +926,10 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
       // 3. merge jumps whose sign disagrees with the values on both sides
       for (int sgi = t; sgi + 1 < nseg; sgi += kTvThreads) {
         const int jp = start[sgi + 1] - 1;
-        if ((double)J[jp] * (val[sgi + 1] - val[sgi]) <= 0.0) { J[jp] = 0; flag_merge = 1; }
+        if ((double)J[jp] * (val[sgi + 1] - val[sgi]) <= 0.0) { J[jp] = 0; flag_merge[fp] = 1; }
       }
       __syncthreads();
-      const int merged = flag_merge;
-      __syncthreads();                                             // everyone has read the flag before it is reset
+      const int merged = flag_merge[fp];                           // (reset again two rounds on, behind several barriers)
       if (merged) continue;
       // 4. split segments whose interior dual leaves [-lam, lam]: per-segment worst violation
       {
@@ -948,12 +956,11 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
           const double u0 = sa == 0 ? 0.0 : -lam * (double)J[sa - 1];
           const double u = u0 + (Pc[i + 1] - Pc[sa]) - (val[sgi] - c) * (double)(i - sa + 1);
           J[i] = u > 0 ? -1 : 1;
-          flag_split = 1;
+          flag_split[fp] = 1;
         }
       }
       __syncthreads();
-      const int split = flag_split;
-      __syncthreads();
+      const int split = flag_split[fp];
       if (!split) { converged = true; break; }
     }
     if (converged) {
@@ -975,8 +982,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
         if (i != c0 && J[i - 1] != 0) ++sgi;
         Pc[i] = val[sgi];                                          // Pc is free now: holds the solution
       }
-      __syncthreads();
-      for (int i = c0; i < c1; ++i) val[i] = Pc[i];
+      sol = Pc;
     } else {
       __syncthreads();
       if (t == 0) tv1d_condat_dev(y, val, n, lam);                 // exact sequential fallback
@@ -985,31 +991,25 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
   __syncthreads();
   // ---- write the column; optionally the ADMM dual update and residual sums for it
   if (fz.Z == nullptr) {
-    for (int i = t; i < n; i += kTvThreads) z[i] = val[i];
+    for (int i = t; i < n; i += kTvThreads) z[i] = sol[i];
     return;
   }
   double* Zc = fz.Z + fz.ld * r;
   double* muc = fz.mu + fz.ld * r;
   double s1 = 0, s2 = 0, s3 = 0, s4 = 0;
   auto dual = [&](auto kper_tag) {
-    constexpr int KP = decltype(kper_tag)::value;      // entries per thread, by the same three size classes as above
-    double mo[KP], zo[KP];
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {                     // all loads first: stores below may alias them
-      const int i = min(t + k * kTvThreads, n - 1);
-      mo[k] = muc[i];
-      zo[k] = Zc[i];
-    }
+    constexpr int KP = decltype(kper_tag)::value;      // entries per thread, by the same size classes as above
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
       const int i = t + k * kTvThreads;
       if (i < n) {
-        const double zn = val[i], vv = y[i];
-        const double x = vv - mo[k];                   // fac = V - mu_old
+        const double zn = sol[i], vv = y[i];
+        const double mo = keep_mu[k < kKeep ? k : 0], zo = keep_z[k < kKeep ? k : 0];   // fetched with the column
+        const double x = vv - mo;                      // fac = V - mu_old
         const double mn = vv - zn;                     // mu + fac - Z   (:1428)
         Zc[i] = zn;
         muc[i] = mn;
-        const double d = x - zn, e = zn - zo[k];
+        const double d = x - zn, e = zn - zo;
         s1 += d * d; s2 += x * x; s3 += mn * mn; s4 += e * e;
       }
     }
@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
       for (int k = 0; k < 4; ++k) {
         const int i = i0 + t + k * kTvThreads;
         if (i < n) {
-          const double zn = val[i], vv = y[i];
+          const double zn = sol[i], vv = y[i];
           const double x = vv - mo[k];
           const double mn = vv - zn;
           Zc[i] = zn;
