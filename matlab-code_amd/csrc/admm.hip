@@ -774,14 +774,14 @@ struct TvFused {
 static __host__ __device__ inline size_t tv_ws_doubles(int64_t rows) {
   return ((size_t)(4 * rows + 2) * 8 + (size_t)(rows + 2) * 4 + (size_t)rows + 64 + 7) / 8;
 }
-template <int kTvThreads, bool GLOBAL = false>
+template <int kTvThreads, int MEM = 0>
 __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const double* warm, int64_t ldw, TvFused fz,
                                                              const AdmmCtl* ctl) {
   CTL_GUARD(ctl);
   constexpr int NW = kTvThreads / 64;
+  constexpr bool GLOBAL = MEM != 0;                                // columns beyond the LDS-resident 4096 rows
   constexpr unsigned long long kIdxMask = GLOBAL ? 0xffffffull : 0xfffull;
   extern __shared__ double lds_dyn[];
-  double* dyn = GLOBAL ? a.ws + (size_t)blockIdx.x * tv_ws_doubles(a.rows) : lds_dyn;
   __shared__ int wsum[NW];
   __shared__ double dsum[NW];
   __shared__ int flag_merge[2], flag_split[2];          // alternate by round: the reset of one never races with the read of the other
@@ -791,12 +791,31 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
   const double* vin = a.V + a.ldv * r;
   double* z = a.Z + a.ldz * r;
   const double lam = a.p0 / (a.rho[0] * a.rho_mul);
-  double* y = dyn;                                                 // n
-  double* Pc = dyn + n;                                            // n + 1
-  double* val = dyn + 2 * n + 1;                                   // n
-  unsigned long long* best = reinterpret_cast<unsigned long long*>(dyn + 3 * n + 1);   // n
-  int* start = reinterpret_cast<int*>(dyn + 4 * n + 1);            // n + 1
-  signed char* J = reinterpret_cast<signed char*>(start + n + 1);  // n
+  // working arrays: y (n), Pc (n + 1), val (n), best (n), start (n + 1 ints), J (n bytes) -- 37 bytes per row.
+  //   MEM 0: all in LDS (<= 4096 rows)
+  //   MEM 2: the arrays every phase of a round walks (Pc, start, J: 13 bytes per row) in LDS, y / val / best in the
+  //          column's slice of the prox workspace (<= kTvHybridMax rows; round 2 had all six in the workspace there and
+  //          every phase was a chain of L2 round trips: 90 us per in-loop call at 6000 rows against 22 us at 2000)
+  //   MEM 1: all in the workspace (L2-resident)
+  double* gws = GLOBAL ? a.ws + (size_t)blockIdx.x * tv_ws_doubles(a.rows) : nullptr;
+  double *y, *Pc, *val;
+  unsigned long long* best;
+  int* start;
+  signed char* J;
+  if constexpr (MEM == 2) {
+    y = gws; val = gws + n; best = reinterpret_cast<unsigned long long*>(gws + 2 * n);
+    Pc = lds_dyn;                                                  // n + 1
+    start = reinterpret_cast<int*>(lds_dyn + n + 1);               // n + 1
+    J = reinterpret_cast<signed char*>(start + n + 1);             // n
+  } else {
+    double* dyn = GLOBAL ? gws : lds_dyn;
+    y = dyn;                                                       // n
+    Pc = dyn + n;                                                  // n + 1
+    val = dyn + 2 * n + 1;                                         // n
+    best = reinterpret_cast<unsigned long long*>(dyn + 3 * n + 1); // n
+    start = reinterpret_cast<int*>(dyn + 4 * n + 1);               // n + 1
+    J = reinterpret_cast<signed char*>(start + n + 1);             // n
+  }
   const int chunk = (n + kTvThreads - 1) / kTvThreads;
   const int c0 = min(n, t * chunk), c1 = min(n, c0 + chunk);
   constexpr int kKeep = GLOBAL ? 1 : kTvParMax / kTvThreads;      // entries per thread of an LDS-resident column (<= 4096 rows)
@@ -1313,13 +1332,22 @@ size_t prox_ws_bytes(int type, int64_t rows, int R) {
   }
 }
 
+// Pc, start and J of a column in LDS (13 bytes per row): up to 12 000 rows beside the kernel's static LDS
+static constexpr int64_t kTvHybridMax = 12000;
+static size_t tv_hybrid_lds(int64_t rows) { return (size_t)(rows + 1) * 8 + (size_t)(rows + 2) * 4 + (size_t)rows + 64; }
 static size_t tv_fast_lds(int64_t rows) { return (size_t)(4 * rows + 2) * 8 + (size_t)(rows + 2) * 4 + (size_t)rows + 64; }
 static void tv_fast_launch(const ColArgs& a, const double* warm, int64_t ldw, const TvFused& fz, const AdmmCtl* ctl,
                            hipStream_t s) {
   if (a.rows > kTvParMax) {
     AO_REQUIRE(a.ws != nullptr && a.rows < (int64_t(1) << 24), "TV prox: %lld rows need the global workspace (below 2^24 rows)",
                (long long)a.rows);
-    prox_tv_fast_k<1024, true><<<a.R, 1024, 0, s>>>(a, warm, ldw, fz, ctl);
+    static const bool all_global = getenv("AOADMM_TV_ALL_GLOBAL") != nullptr;   // development switch (tools/time_tv_long*.py)
+    if (a.rows <= kTvHybridMax && !all_global) {
+      ensure_dynamic_lds(reinterpret_cast<const void*>(prox_tv_fast_k<1024, 2>), (int)tv_hybrid_lds(kTvHybridMax));
+      prox_tv_fast_k<1024, 2><<<a.R, 1024, tv_hybrid_lds(a.rows), s>>>(a, warm, ldw, fz, ctl);
+    } else {
+      prox_tv_fast_k<1024, 1><<<a.R, 1024, 0, s>>>(a, warm, ldw, fz, ctl);
+    }
   } else if (a.rows > 1024) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(prox_tv_fast_k<1024>), (int)tv_fast_lds(kTvParMax));
     prox_tv_fast_k<1024><<<a.R, 1024, tv_fast_lds(a.rows), s>>>(a, warm, ldw, fz, ctl);
