@@ -65,9 +65,11 @@ def test_config2_500cube_fp32_tensor_mode_vs_oracle(pkg, eng):
 
 def test_config5_2000cube_fp32_vs_fp64_factor_drift(pkg):
     """config 5 itself: the same synthetic 2000^3 tensor (generated in HBM from the same seed) solved in the fp32-tensor
-    mode and in the fp64 parity mode, 10 outer iterations each from the same init; the factors of the two runs are
-    compared.  Stated tolerance 1e-6 relative Frobenius (measured 5e-8 / 2e-8 / 5e-9 for the three modes, DESIGN.md
-    section 2); the two runs need 96 GB and 192 GB of HBM one after the other."""
+    mode and in the fp64 parity mode, 25 outer iterations each from the same init (what `bench.py` runs: 5 warm-up + 20
+    timed); the factors of the two runs are compared.  Stated tolerance: north_star's 1e-8 relative Frobenius -- measured
+    5.3e-9 / 3.0e-9 / 6.9e-10 for the three modes with the two-level accumulation of round 3 (6.1e-8 / 2.0e-8 / 8.5e-9
+    with one fp32 accumulation run per contraction); the two runs need 96 GB and 192 GB of HBM one
+    after the other."""
     import bench
     n, R = 2000, 20
     facs = {}
@@ -80,12 +82,12 @@ def test_config5_2000cube_fp32_vs_fp64_factor_drift(pkg):
             pkg.build_model(e, Z, prec)
             G = pkg.init_coupled_AOADMM_CMTF(Z, io, rng=rng, engine=e)
             pkg.upload_state(e, Z, G)
-            pkg.run_solver(e, dict(MaxOuterIters=10, MaxInnerIters=5, AbsFuncTol=0.0, OuterRelTol=0.0, innerRelPrTol_coupl=0.0,
+            pkg.run_solver(e, dict(MaxOuterIters=25, MaxInnerIters=5, AbsFuncTol=0.0, OuterRelTol=0.0, innerRelPrTol_coupl=0.0,
                                    innerRelPrTol_constr=0.0, innerRelDualTol_coupl=0.0, innerRelDualTol_constr=0.0, bsum=0), 3)
             facs[prec] = pkg.download_state(e, Z, G)['fac']
     drift = [rel_fro(a, b) for a, b in zip(facs['f32'], facs['f64'])]
-    print('fp32-vs-fp64 factor drift at 2000^3 after 10 iterations:', drift)
-    assert max(drift) < 1e-6, drift
+    print('fp32-vs-fp64 factor drift at 2000^3 after 25 iterations:', drift)
+    assert max(drift) < 1e-8, drift
 
 
 def test_config4_parafac2_256_slabs(pkg, eng):
