@@ -95,6 +95,7 @@ struct SmallMttkrp {
   int64_t ldOut;
 };
 bool small_mttkrp_ok(int64_t elems, int nd, const int64_t* dims, int R);
-void small_mttkrp(const SmallMttkrp& a, int prec, int64_t rows, hipStream_t s);
+// `sys`: as for the reductions over T -- the mode's system build as one extra workgroup; true when it rode
+bool small_mttkrp(const SmallMttkrp& a, int prec, int64_t rows, hipStream_t s, const SysBuild* sys = nullptr);
 
 }  // namespace aoadmm

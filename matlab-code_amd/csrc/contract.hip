@@ -1253,8 +1253,10 @@ bool launch_reduce_outer(const void* T, int tprec, int nchunk, int64_t trows, in
 // (fixed order).  Accumulation in fp64 whatever the tensor's precision.
 // ---------------------------------------------------------------------------
 template <typename TT, int RMAX>
-__global__ __launch_bounds__(256) void small_mttkrp_k(SmallMttkrp a) {
+__global__ __launch_bounds__(256) void small_mttkrp_k(SmallMttkrp a, int has_sys, SysBuild sys) {
   extern __shared__ double sf[];                     // Fa [Na][R] | Fb [Nb][R] | red [4][RMAX]
+  if (has_sys && blockIdx.x == 0) { sys_build_rider(sys); return; }   // the mode's R x R system rides along (small_dev.h)
+  const int row = (int)blockIdx.x - has_sys;
   const int R = a.R, Na = a.Na, Nb = a.Nb;
   double* fa = sf;
   double* fb = sf + (size_t)Na * R;
@@ -1262,7 +1264,7 @@ __global__ __launch_bounds__(256) void small_mttkrp_k(SmallMttkrp a) {
   for (int e = threadIdx.x; e < Na * R; e += 256) { const int i = e / R, r = e - i * R; fa[e] = a.Fa[i + a.lda * r]; }
   for (int e = threadIdx.x; e < Nb * R; e += 256) { const int i = e / R, r = e - i * R; fb[e] = a.Fb ? a.Fb[i + a.ldb * r] : 1.0; }
   __syncthreads();
-  const TT* X = reinterpret_cast<const TT*>(a.X) + (int64_t)blockIdx.x * a.sn;
+  const TT* X = reinterpret_cast<const TT*>(a.X) + (int64_t)row * a.sn;
   double acc[RMAX];
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) acc[r] = 0.0;
@@ -1284,7 +1286,7 @@ __global__ __launch_bounds__(256) void small_mttkrp_k(SmallMttkrp a) {
   if ((int)threadIdx.x < R) {
     const int r = threadIdx.x;
     const double tot = (red[r] + red[RMAX + r]) + (red[2 * RMAX + r] + red[3 * RMAX + r]);
-    a.out[blockIdx.x + a.ldOut * r] = a.scale * tot;
+    a.out[row + a.ldOut * r] = a.scale * tot;
   }
 }
 
@@ -1298,16 +1300,20 @@ bool small_mttkrp_ok(int64_t elems, int nd, const int64_t* dims, int R) {
   return (size_t)(sum * R + 64) * sizeof(double) <= 40 * 1024;
 }
 
-void small_mttkrp(const SmallMttkrp& a, int prec, int64_t rows, hipStream_t s) {
+bool small_mttkrp(const SmallMttkrp& a, int prec, int64_t rows, hipStream_t s, const SysBuild* sys) {
+  if (!sys_can_ride(sys)) sys = nullptr;
+  const int hs = sys ? 1 : 0;
+  const SysBuild sb = sys ? *sys : SysBuild();
   AO_REQUIRE(a.R >= 1 && a.R <= 16 && rows >= 1 && a.Na >= 1 && a.Nb >= 1, "small_mttkrp: bad sizes");
   const int rmax = a.R <= 4 ? 4 : (a.R <= 8 ? 8 : 16);
   const size_t lds = ((size_t)(a.Na + a.Nb) * a.R + 4 * rmax) * sizeof(double);
   AO_REQUIRE(lds <= 48 * 1024, "small_mttkrp: factors do not fit LDS");
-#define AO_SM(TT, RM) small_mttkrp_k<TT, RM><<<(unsigned)rows, 256, lds, s>>>(a)
+#define AO_SM(TT, RM) small_mttkrp_k<TT, RM><<<(unsigned)(rows + hs), 256, lds, s>>>(a, hs, sb)
   if (prec == AOADMM_PREC_F32) { if (rmax == 4) AO_SM(float, 4); else if (rmax == 8) AO_SM(float, 8); else AO_SM(float, 16); }
   else { if (rmax == 4) AO_SM(double, 4); else if (rmax == 8) AO_SM(double, 8); else AO_SM(double, 16); }
 #undef AO_SM
   AO_KERNEL_CHECK();
+  return sys != nullptr;
 }
 
 template <typename TT>

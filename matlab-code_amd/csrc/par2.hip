@@ -374,6 +374,230 @@ __device__ __forceinline__ void par2_deltab_part_dev(const P2BArgs& a, const P2D
     a.part[(int64_t)k * RR + e] = a.rho[k] * acc;
   }
 }
+// The same three steps for SHORT slabs (J_k <= 64 * NR rows, R <= RMAX <= 4) with the slab in registers: lane l owns rows
+// l, l + 64, ...; B_k, mu_k, P_k, W_k of those rows, the slab's Cholesky factor, DeltaB and the Jacobi rotation never
+// leave the register file between the steps.  The version above hands W, B, P from step to step through global memory
+// and LDS (three dependent memory round trips and two workgroup barriers per call, the column products of every
+// rotation read from LDS): 16-24 us per call at R = 3, 44 % of an outer iteration of BASELINE config 4.  Here a rotation
+// is three lane-local products, three DPP wave sums (bit-identical in every lane, so every lane derives the same
+// rotation) and a lane-local update.  Same arithmetic in the same order as par2_polar_dev (sums over a lane's rows first,
+// then the wave), hence the same polar factor to the last bit; the DeltaB contribution sums in wave order instead of
+// lane groups (a rounding-level difference).
+template <int RMAX, int NR>
+__device__ __forceinline__ void par2_b_slab_regs_dev(const P2BArgs& a, const P2Dims& d, int k) {
+  const int R = d.R, lane = threadIdx.x;
+  const int64_t o = d.off[k];
+  const int Jk = (int)(d.off[k + 1] - o);
+  const int64_t base = o * R;
+  // ---- every global load of the call in one round trip (clamped addresses, no exec-mask branches in between)
+  double Lr[RMAX][RMAX], Dr[RMAX][RMAX], Jr[RMAX][RMAX];
+  const bool warm = a.Jrot != nullptr && a.jrot_valid;
+#pragma unroll
+  for (int c = 0; c < RMAX; ++c)
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      const bool in = r < R && c < R;
+      const int e = in ? r + R * c : 0;
+      Lr[r][c] = a.L[(int64_t)k * R * R + e];
+      Dr[r][c] = a.DeltaB[e];
+      const double jw = warm ? a.Jrot[(int64_t)k * R * R + e] : ((r == c) ? 1.0 : 0.0);
+      Jr[r][c] = in ? jw : ((r == c) ? 1.0 : 0.0);
+    }
+  const double rhok = a.rho[k];
+  double pv[NR][RMAX], ak[NR][RMAX], mu[NR][RMAX], zc[NR][RMAX];
+  bool have[NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int j = lane + 64 * u;
+    have[u] = j < Jk;
+    const int jc = have[u] ? j : 0;
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const int64_t at = base + jc + (int64_t)Jk * (q < R ? q : 0);
+      pv[u][q] = a.P[at]; ak[u][q] = a.Ak[at]; mu[u][q] = a.mu[at];
+      zc[u][q] = a.use_constr ? a.Z[at] - a.muZ[at] : 0.0;
+    }
+  }
+  const double rh = rhok / 2;
+  double bm[NR][RMAX], w[NR][RMAX];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    double x[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      x[r] = 0.0;
+      if (r < R) {
+        double pd = 0.0;
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q)
+          if (q < R) pd += pv[u][q] * Dr[q][r];                                           // (P_k*DeltaB)(j,r)
+        double v = ak[u][r] + rh * (pd - mu[u][r]);
+        if (a.use_constr) v += rh * zc[u][r];                                             // :527-529
+        x[r] = v;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {                    // forward: x*L' = rhs
+      if (r < R) {
+        double v = x[r];
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q)
+          if (q < r) v -= Lr[r][q] * x[q];
+        x[r] = v / Lr[r][r];
+      }
+    }
+#pragma unroll
+    for (int r = RMAX - 1; r >= 0; --r) {               // backward: x*L = y
+      if (r < R) {
+        double v = x[r];
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q)
+          if (q > r && q < R) v -= Lr[q][r] * x[q];
+        x[r] = v / Lr[r][r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      bm[u][r] = 0.0;
+      if (r < R) {
+        bm[u][r] = have[u] ? x[r] + mu[u][r] : 0.0;
+        if (have[u]) {
+          const int64_t at = base + lane + 64 * u + (int64_t)Jk * r;
+          a.B[at] = x[r];
+          a.Pold[at] = pv[u][r];
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {                    // W(j,r) = sum_q (B+mu)(j,q) * DeltaB(r,q); rows past J_k: zero
+      double v = 0.0;
+      if (r < R) {
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q)
+          if (q < R) v += bm[u][q] * Dr[r][q];
+      }
+      w[u][r] = v;
+    }
+  }
+  // ---- polar factor of W_k by one-sided Jacobi (:532-534), as par2_polar_dev
+  if (warm) {
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      double t[RMAX];
+#pragma unroll
+      for (int p = 0; p < RMAX; ++p) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q)
+          if (q < R) acc += w[u][q] * Jr[q][p];
+        t[p] = acc;
+      }
+#pragma unroll
+      for (int p = 0; p < RMAX; ++p)
+        if (p < R) w[u][p] = t[p];
+    }
+  }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    bool rotated = false;
+#pragma unroll
+    for (int p = 0; p < RMAX - 1; ++p)
+#pragma unroll
+      for (int q = p + 1; q < RMAX; ++q) {
+        if (q < R) {                                   // uniform
+          double al = 0, be = 0, ga = 0;
+#pragma unroll
+          for (int u = 0; u < NR; ++u) { al += w[u][p] * w[u][p]; be += w[u][q] * w[u][q]; ga += w[u][p] * w[u][q]; }
+          al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
+          if (ga != 0.0 && fabs(ga) > 1e-15 * sqrt(al * be)) {           // uniform over the wave
+            const double zeta = (be - al) / (2.0 * ga);
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + t * t);
+            const double sn = c * t;
+            rotated = true;
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+              const double x = w[u][p], y = w[u][q];
+              w[u][p] = c * x - sn * y;
+              w[u][q] = sn * x + c * y;
+            }
+#pragma unroll
+            for (int i = 0; i < RMAX; ++i) {
+              const double x = Jr[i][p], y = Jr[i][q];
+              Jr[i][p] = c * x - sn * y;
+              Jr[i][q] = sn * x + c * y;
+            }
+          }
+        }
+      }
+    if (!rotated) break;
+  }
+#pragma unroll
+  for (int p = 0; p < RMAX; ++p) {
+    if (p < R) {
+      double al = 0;
+#pragma unroll
+      for (int u = 0; u < NR; ++u) al += w[u][p] * w[u][p];
+      const double sg = sqrt(wave_sum(al));
+#pragma unroll
+      for (int u = 0; u < NR; ++u) w[u][p] = sg > 0 ? w[u][p] / sg : 0.0;
+    }
+  }
+  if (a.Jrot != nullptr && lane == 0) {
+#pragma unroll
+    for (int c = 0; c < RMAX; ++c)
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r)
+        if (r < R && c < R) a.Jrot[(int64_t)k * R * R + r + R * c] = Jr[r][c];
+  }
+  // P_k = U * Jr'  and this slab's DeltaB contribution  rho_k * P_k' * (B_k + mu_k)   (:541)
+  double pn[NR][RMAX];
+#pragma unroll
+  for (int u = 0; u < NR; ++u)
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      double acc = 0.0;
+      if (r < R) {
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q)
+          if (q < R) acc += w[u][q] * Jr[r][q];
+        if (have[u]) a.P[base + lane + 64 * u + (int64_t)Jk * r] = acc;
+      }
+      pn[u][r] = have[u] ? acc : 0.0;
+    }
+  double tot[RMAX][RMAX];
+#pragma unroll
+  for (int q = 0; q < RMAX; ++q)
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+      tot[r][q] = 0.0;
+      if (r < R && q < R) {
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) acc += pn[u][r] * bm[u][q];
+        tot[r][q] = wave_sum(acc);
+      }
+    }
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q)
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r)
+        if (r < R && q < R) a.part[(int64_t)k * R * R + r + R * q] = rhok * tot[r][q];
+  }
+}
+constexpr int kP2RegsMaxR = 4;
+// rows per lane of the register form for a block whose longest slab has Jmax rows (0: not applicable)
+static int par2_regs_rows(const P2Dims& d) {
+  static const bool off = getenv("AOADMM_NO_PAR2_REGS") != nullptr;           // development switch
+  if (off || d.R > kP2RegsMaxR) return 0;
+  return d.Jmax <= 64 ? 1 : (d.Jmax <= 128 ? 2 : (d.Jmax <= 256 ? 4 : 0));
+}
+template <int NR>
+__global__ __launch_bounds__(kP2Threads) void par2_b_slab_regs_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl) {
+  CTL_GUARD(ctl);
+  par2_b_slab_regs_dev<kP2RegsMaxR, NR>(a, d, d.k0 + blockIdx.x);
+}
+
 // primal update, polar factor and DeltaB contribution of slab k in one launch
 template <int RMAX>
 __global__ __launch_bounds__(kP2Threads) void par2_b_slab_k(P2BArgs a, P2Dims d, const AdmmCtl* ctl, int in_lds) {
@@ -492,6 +716,11 @@ __global__ __launch_bounds__(kP2Threads) void par2_b_slab_fold_k(P2BArgs a, P2Di
   par2_polar_dev(a.W, a.P, d, k, in_lds, sh, a.Jrot, a.jrot_valid);
   __syncthreads();
   par2_deltab_part_dev(a, d, k, sh);
+}
+template <int NR>
+__global__ __launch_bounds__(kP2Threads) void par2_b_slab_fold_regs_k(P2BArgs a, P2Dims d, AdmmCtl* ctl, P2Fold f) {
+  if (!par2_b_head(a.norms, d, f, ctl, blockIdx.x == 0 && threadIdx.x == 0)) return;   // the same in every workgroup
+  par2_b_slab_regs_dev<kP2RegsMaxR, NR>(a, d, d.k0 + blockIdx.x);
 }
 // a.DeltaB: DeltaB of this iteration (read); a.DeltaBold: receives the new one
 template <int RRMAX>
@@ -619,7 +848,11 @@ void par2_b_loop_folded(const P2BArgs& a0, const P2Dims& d, AdmmCtl* ctl, int ma
     a.DeltaBold = (it & 1) ? a0.DeltaB : a0.DeltaBold;
     a.jrot_valid = it >= 1 ? 1 : 0;                  // the first inner iteration of every loop starts cold
     f.it = it;
-    if (d.R <= 4) par2_b_slab_fold_k<4><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds, f);
+    const int nr = par2_regs_rows(d);
+    if (nr == 1) par2_b_slab_fold_regs_k<1><<<nk, kP2Threads, 0, s>>>(a, d, ctl, f);
+    else if (nr == 2) par2_b_slab_fold_regs_k<2><<<nk, kP2Threads, 0, s>>>(a, d, ctl, f);
+    else if (nr == 4) par2_b_slab_fold_regs_k<4><<<nk, kP2Threads, 0, s>>>(a, d, ctl, f);
+    else if (d.R <= 4) par2_b_slab_fold_k<4><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds, f);
     else par2_b_slab_fold_k<8><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds, f);
     AO_KERNEL_CHECK();
     if (RR <= 16) par2_b_dual_fold_k<16><<<nk, kP2Threads, lds2, s>>>(a, d, ctl);
@@ -638,7 +871,11 @@ void par2_b_iteration(const P2BArgs& a, const P2Dims& d, const AdmmCtl* ctl, hip
   const size_t wl = (size_t)d.Jmax * d.R * sizeof(double);
   const int in_lds = rr + wl <= 48 * 1024;
   const size_t lds = std::max<size_t>(std::max<size_t>(2 * rr, rr + (in_lds ? wl : 0)), 64 * sizeof(double));
-  if (d.R <= 4) par2_b_slab_k<4><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds);
+  const int nr = par2_regs_rows(d);
+  if (nr == 1) par2_b_slab_regs_k<1><<<nk, kP2Threads, 0, s>>>(a, d, ctl);
+  else if (nr == 2) par2_b_slab_regs_k<2><<<nk, kP2Threads, 0, s>>>(a, d, ctl);
+  else if (nr == 4) par2_b_slab_regs_k<4><<<nk, kP2Threads, 0, s>>>(a, d, ctl);
+  else if (d.R <= 4) par2_b_slab_k<4><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds);
   else if (d.R <= 8) par2_b_slab_k<8><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds);
   else if (d.R <= 16) par2_b_slab_k<16><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds);
   else par2_b_slab_k<kMaxRank><<<nk, kP2Threads, lds, s>>>(a, d, ctl, in_lds);

@@ -1284,7 +1284,8 @@ void Engine::block_mttkrp(CpBlock& b, int pos, const FactorRef* facs, int R, dou
     if (b.nd == 3) { sm.sb = st[ib]; sm.Nb = (int)ext[ib]; sm.Fb = facs[ib].p; sm.ldb = facs[ib].ld; }
     else { sm.sb = 0; sm.Nb = 1; sm.Fb = nullptr; sm.ldb = 0; }
     sm.R = R; sm.scale = scale; sm.out = out; sm.ldOut = ldOut;
-    small_mttkrp(sm, prec, ext[pos], stream_);
+    const bool rode = small_mttkrp(sm, prec, ext[pos], stream_, sys);
+    if (sys_done) *sys_done = rode;
     return;
   }
   if (b.nd == 2) {
