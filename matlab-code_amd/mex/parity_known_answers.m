@@ -6,7 +6,7 @@
 %     python tests/golden/make_golden.py --export-mat DIR
 % The development container has no MATLAB: this script has never been executed there.
 function parity_known_answers(dir_mat)
-cases = {'script1','script13','script14','script10'};
+cases = {'script1','script13','script14','script10','script12'};
 for c = 1:numel(cases)
     S = load(fullfile(dir_mat, [cases{c} '.mat']));
     [Z, G0, options] = build_case(cases{c}, S);
@@ -60,6 +60,13 @@ switch name
         H = cell(6,1); H{1} = eye(20); H{6} = zeros(20,40); for i = 1:20, H{6}(i, 2*i-1) = 1; end
         Z.coupling.lin_coupled_modes = [1 0 0 0 0 1]; Z.coupling.coupling_type = 1; Z.coupling.coupl_trafo_matrices = H;
         Z.constrained_modes = [1 1 1 1 0 1]; Z.constraints = {nn,nn,nn,nn,[],nn}; Z.weights = [1/2 1/2];
+    case 'script12'
+        K = size(S.truth_C, 1);
+        Z.model = {'CP','PAR2'}; Z.modes = {[1 2 3],[4 5 6]}; Z.size = {20,30,40,20,25*ones(1,K),K};
+        Z.coupling.lin_coupled_modes = [1 0 0 1 0 0]; Z.coupling.coupling_type = 0; Z.coupling.coupl_trafo_matrices = cell(6,1);
+        Z.constrained_modes = [0 0 0 0 0 0]; Z.constraints = cell(6,1); Z.weights = [1/2 1/2];
+        Z.miss{1} = sptensor(tensor(double(S.miss_1)));                                   % example_script12_CP_PAR2_EM.m:108-113
+        Z.miss{2} = arrayfun(@(k) logical(squeeze(S.miss_2(k,:,:))), 1:K, 'UniformOutput', false)';
     case 'script10'
         Z.model = {'CP'}; Z.modes = {[1 2 3]}; Z.size = {60,50,70};
         Z.coupling.lin_coupled_modes = [0 0 0]; Z.coupling.coupling_type = []; Z.coupling.coupl_trafo_matrices = cell(3,1);

@@ -11,6 +11,10 @@ The reference holds no output vectors, but four of its scripts state a result by
   script 14  CP 20x30x40 + PARAFAC2 (I = 20, K = 40), CP mode 1 coupled to the PARAFAC2 C mode with type 1 (H*C = Delta,
              every second row), noise 0 (example_script14_..._doublesamplingrate.m:19-41, :24): Fit -> 100 %, FMS -> 1
              (:135-160)
+  script 12  CP 20x30x40 + PARAFAC2 (I = 20, K = 30 slabs of 25 columns), R = 3, exact coupling, 5 % noise, 20 % of the
+             entries of both blocks missing at random and initialised with 0, EM imputation
+             (example_script12_CP_PAR2_EM.m:17-40,100-147): the generating factors are recovered and the imputed model
+             reproduces the held-out entries to the noise level (bars measured on the oracle first)
   script 10  CP 60x50x70, R = 3, piecewise-constant first mode (four jumps per component), noise 0.8, TV(0.001) on
              mode 1 and l2-ball(1) on modes 2-3 (example_script10_CP_TVreg.m:21-57,
              create_CP_data_example10piecewiseconstant.m): the generating factors are recovered (FMS bar measured on the
@@ -78,6 +82,31 @@ def script14_truth(rng):
     AA = rng.standard_normal((30, R))
     return dict(A1=A1, A2=rng.random((30, R)), A3=rng.random((40, R)), A4=rng.random((20, R)),
                 B=np.stack([np.roll(AA, k, axis=0) for k in range(K)]), C=C)
+
+
+def script12_truth(rng):
+    R, K = 3, 30
+    A = rng.standard_normal((20, R))                             # modes 1 and 4, exactly coupled; every factor randn but C
+    A2, A3 = rng.standard_normal((30, R)), rng.standard_normal((40, R))
+    AA = rng.standard_normal((25, R))
+    B = np.stack([np.roll(AA, k, axis=0) for k in range(K)])
+    C = rng.random((K, R)) + 0.1
+    X1 = _ktensor([A, A2, A3])
+    N = rng.standard_normal(X1.shape)
+    X1n = X1 + 0.05 * np.linalg.norm(X1) / np.linalg.norm(N) * N
+    Xk = np.stack([A @ np.diag(C[k]) @ B[k].T for k in range(K)])
+    Xkn = np.empty_like(Xk)
+    for k in range(K):                                           # per-slab noise level (create_coupled_data.m:145-151)
+        Nk = rng.standard_normal(Xk[k].shape)
+        Xkn[k] = Xk[k] + 0.05 * np.linalg.norm(Xk[k]) / np.linalg.norm(Nk) * Nk
+    M1 = np.ones(X1.shape, dtype=bool)
+    M1.flat[rng.permutation(M1.size)[:round(0.2 * M1.size)]] = False
+    Mk = np.ones(Xk.shape, dtype=bool)
+    for k in range(K):
+        mk = np.ones(Xk[k].size, dtype=bool)
+        mk[rng.permutation(mk.size)[:round(0.2 * mk.size)]] = False
+        Mk[k] = mk.reshape(Xk[k].shape)
+    return dict(A1=A, A2=A2, A3=A3, B=B, C=C, X1clean=X1, Xkclean=Xk, X1=X1n, Xk=Xkn, M1=M1, Mk=Mk)
 
 
 def script10_truth(rng):
@@ -154,6 +183,21 @@ def script14_model(t):
     return Z, [n1, n2]
 
 
+def script12_model(t):
+    n1 = np.linalg.norm(t['X1'])
+    n2 = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in t['Xk']))
+    K = t['C'].shape[0]
+    M1 = np.asarray(t['M1']).astype(bool)
+    Mk = [np.asarray(m).astype(bool) for m in t['Mk']]
+    X1 = t['X1'] / n1
+    X1 = np.where(M1, X1, 0.0)                                   # missing entries initialised with 0 (:143-147)
+    Xk = [np.where(Mk[k], t['Xk'][k] / n2, 0.0) for k in range(K)]
+    Z = dict(loss_function=['Frobenius'] * 2, model=['CP', 'PAR2'], modes=[[1, 2, 3], [4, 5, 6]],
+             size=[20, 30, 40, 20, [25] * K, K], coupling=_coupling(6, [1, 0, 0, 1, 0, 0], [0]),
+             constrained_modes=[0] * 6, constraints=[None] * 6, weights=[0.5, 0.5], object=[X1, Xk], miss=[M1, Mk])
+    return Z, [n1, n2]
+
+
 def script10_model(t):
     X = t['X']
     n1 = np.linalg.norm(X)
@@ -181,6 +225,9 @@ CASES = {
     'script14': dict(truth=script14_truth, model=script14_model,
                      distr=['rand+0.1', 'rand', 'rand', 'rand', 'randn', 'rand+0.1'], lambdas=[[1] * 3, [1] * 3],
                      options=script_options(10000, 1e-7, 1e-5), seeds=(114, 214)),
+    'script12': dict(truth=script12_truth, model=script12_model,
+                     distr=['randn', 'randn', 'randn', 'randn', 'randn', 'rand+0.1'], lambdas=[[1] * 3, [1] * 3],
+                     options=script_options(4000, 1e-7, 1e-5), seeds=(12, 22)),
     'script10': dict(truth=script10_truth, model=script10_model, distr=['randn', 'randn', 'randn'], lambdas=[[1] * 3],
                      options=script_options(4000, 1e-7, 1e-5), seeds=(110, 210)),
 }
@@ -282,6 +329,25 @@ def evaluate(name, t, Z, Fac):
     """Fits (per block, %) and factor match scores against the generating factors, as the scripts compute them."""
     f = Fac['fac']
     res = {}
+    if name == 'script12':
+        # factor match scores as the script computes them, and the held-out entries against the NOISE-FREE data
+        res['FMS1'] = fms(f[0:3], [t['A1'], t['A2'], t['A3']])
+        res['FMS2_A'] = fms([f[3]], [t['A1']])
+        res['FMS2_C'] = fms([f[5]], [t['C']])
+        res['FMS2_B'] = fms([np.vstack(f[4])], [np.vstack(list(t['B']))])
+        n1 = np.linalg.norm(t['X1'])
+        n2 = np.sqrt(sum(np.linalg.norm(x) ** 2 for x in t['Xk']))
+        M1 = np.asarray(t['M1']).astype(bool)
+        Mh = _ktensor(f[0:3])
+        res['Err_heldout1'] = np.linalg.norm((Mh - t['X1clean'] / n1)[~M1]) / np.linalg.norm((t['X1clean'] / n1)[~M1])
+        num = den = 0.0
+        for k in range(t['C'].shape[0]):
+            mk = ~np.asarray(t['Mk'][k]).astype(bool)
+            mod = f[3] @ np.diag(f[5][k]) @ f[4][k].T
+            num += np.linalg.norm((mod - t['Xkclean'][k] / n2)[mk]) ** 2
+            den += np.linalg.norm((t['Xkclean'][k] / n2)[mk]) ** 2
+        res['Err_heldout2'] = np.sqrt(num / den)
+        return res
     if name in ('script1', 'script14'):
         res['Fit1'] = cp_fit(Z['object'][0], f[0:3])
         res['Fit2'] = par2_fit(Z['object'][1], f[3], f[4], f[5])

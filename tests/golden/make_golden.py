@@ -93,6 +93,8 @@ def known_answers_main(export_mat=None):
             m.update({'init_' + k: v for k, v in KA.pack_state(G).items()})
             for p, obj in enumerate(Z['object']):
                 m['object_%d' % (p + 1)] = np.stack(obj) if isinstance(obj, list) else np.asarray(obj)
+            for p, mk in enumerate(Z.get('miss') or []):          # Z.miss{p}: 1 = observed
+                m['miss_%d' % (p + 1)] = (np.stack(mk) if isinstance(mk, list) else np.asarray(mk)).astype(np.uint8)
             m['options'] = {k: v for k, v in opt.items()}
             sio.savemat(os.path.join(export_mat, name + '.mat'), m, do_compression=True)
     np.savez_compressed(os.path.join(HERE, 'known_answers.npz'), **store)
