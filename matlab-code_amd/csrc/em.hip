@@ -16,7 +16,6 @@ namespace aoadmm {
 
 template <typename T, int VEC> struct EmVec;
 template <> struct EmVec<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
-template <> struct EmVec<float, 2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct EmVec<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
 
 // Z.miss as one bit per entry (bit e of the padded layout in byte e >> 3, position e & 7), 1 = observed.  A thread's VEC
@@ -82,15 +81,6 @@ __device__ __forceinline__ XV em_row_dot(const XV* areg, const T* brow, XV m) {
     XV o;
     o.xy = m01; o.zw = m23;
     return o;
-  } else if constexpr (std::is_same<T, float>::value && VEC == 2) {
-    em_f2 m2 = m;
-#pragma unroll
-    for (int r = 0; r < RMAX; r += 2) {
-      const em_f2 b2 = *reinterpret_cast<const em_f2*>(brow + r);
-      m2 = pk_fma_lo(areg[r], b2, m2);
-      m2 = pk_fma_hi(areg[r + 1], b2, m2);
-    }
-    return m2;
   } else {
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
@@ -114,13 +104,6 @@ __device__ __forceinline__ void em_row_axpy(XV* tacc, const T* brow, XV x) {
       const em_f2 b2 = *reinterpret_cast<const em_f2*>(brow + r);
       tacc[r].xy = pk_fma_lo(x01, b2, tacc[r].xy); tacc[r].zw = pk_fma_lo(x23, b2, tacc[r].zw);
       tacc[r + 1].xy = pk_fma_hi(x01, b2, tacc[r + 1].xy); tacc[r + 1].zw = pk_fma_hi(x23, b2, tacc[r + 1].zw);
-    }
-  } else if constexpr (std::is_same<T, float>::value && VEC == 2) {
-#pragma unroll
-    for (int r = 0; r < RMAX; r += 2) {
-      const em_f2 b2 = *reinterpret_cast<const em_f2*>(brow + r);
-      tacc[r] = pk_fma_lo(x, b2, tacc[r]);
-      tacc[r + 1] = pk_fma_hi(x, b2, tacc[r + 1]);
     }
   } else {
 #pragma unroll
@@ -153,7 +136,7 @@ __device__ __forceinline__ void em_row_axpy(XV* tacc, const T* brow, XV x) {
 //     tensor pass the next outer iteration would start with (contract.h ContractPlan: T is [chunk][i + Ipad*f][R]
 //     in the tensor's precision, one chunk per piece of the walk)
 template <typename T, int VEC, int RMAX, bool FUSE>
-__global__ __launch_bounds__(kEmThreads, FUSE ? (VEC * sizeof(T) == 8 ? 3 : 2) : 1) void em_cp_vec_k(EmCpArgs a, int jchunks, int64_t jlen, double* ws) {
+__global__ __launch_bounds__(kEmThreads, FUSE ? 2 : 1) void em_cp_vec_k(EmCpArgs a, int jchunks, int64_t jlen, double* ws) {
   typedef typename EmVec<T, VEC>::type XV;
   typedef uint8_t MV;                                                    // the byte that holds this thread's VEC mask bits
   constexpr unsigned kFull = (1u << VEC) - 1u;
@@ -211,7 +194,7 @@ __global__ __launch_bounds__(kEmThreads, FUSE ? (VEC * sizeof(T) == 8 ? 3 : 2) :
     __syncthreads();
     const int nj = (int)((jend - j0 < kEmJTile) ? (jend - j0) : kEmJTile);
     if (!in_range) continue;
-    constexpr int PD = VEC * sizeof(T) == 8 ? 8 : 4;   // columns in flight (8-byte vectors: twice as many)
+    constexpr int PD = 4;                              // columns in flight
     XV xq[PD]; MV mq[PD];
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
@@ -256,14 +239,10 @@ __global__ __launch_bounds__(kEmThreads, FUSE ? (VEC * sizeof(T) == 8 ? 3 : 2) :
             // s = the first lane's 16-byte slot inside its line; lines cut by the wave's ends go back if this wave's part
             // of them has a missing entry.
             XV* dst = reinterpret_cast<XV*>(X + i0 + step * (j0 + jc));
-            constexpr int VB = VEC * (int)sizeof(T);                       // bytes per lane: 16 or 8
-            constexpr unsigned LPL = 128 / VB;                             // lanes per 128-byte line: 8 or 16
-            constexpr unsigned long long kGrp = (1ull << LPL) - 1ull;
             const unsigned long long bal = __ballot(mv != kFull);
-            const unsigned s16 = (unsigned)(((reinterpret_cast<uintptr_t>(dst) / VB) - (unsigned)lane) & (LPL - 1u));
-            const unsigned g = ((unsigned)lane + s16) / LPL;
-            const unsigned long long grp = g < 64 / LPL ? ((bal << s16) >> (LPL * g)) & kGrp
-                                                        : (s16 ? (bal >> (64 - s16)) & kGrp : 0ull);
+            const unsigned s16 = (unsigned)(((reinterpret_cast<uintptr_t>(dst) >> 4) - (unsigned)lane) & 7u);
+            const unsigned g = ((unsigned)lane + s16) >> 3;
+            const unsigned grp = g < 8 ? (unsigned)((bal << s16) >> (8 * g)) & 0xffu : (unsigned)(bal >> (64 - s16)) & 0xffu;
             if (grp) __builtin_nontemporal_store(xn, dst);
           }
           if constexpr (FUSE) em_row_axpy<T, VEC, RMAX, XV>(tacc, &Bsh[jc][0], xn);
@@ -400,14 +379,7 @@ static void em_chunking(int64_t strips, int64_t NW, int64_t NF, bool fuse, int* 
 }
 
 static bool em_wide(const EmCpArgs& a) { return a.R <= 32; }
-// rows per thread.  fp32: 4 (16-byte vectors) -- or 2 for a FUSED pass of rank > 12 when AOADMM_EM_VEC=2: the fused kernel
-// holds 2*R register vectors per thread and is bound by bytes in flight per wave, halving the vector halves them
-static int em_vec32(const EmCpArgs& a, bool fuse) {
-  static const int forced = [] { const char* e = getenv("AOADMM_EM_VEC"); return e ? atoi(e) : 0; }();
-  if (forced == 2 && fuse && a.R > 12) return 2;
-  return 4;
-}
-static int em_vec(const EmCpArgs& a, int prec, bool fuse) { return !em_wide(a) ? 1 : (prec == AOADMM_PREC_F32 ? em_vec32(a, fuse) : 2); }
+static int em_vec(const EmCpArgs& a, int prec) { return !em_wide(a) ? 1 : (prec == AOADMM_PREC_F32 ? 4 : 2); }
 
 bool em_cp_can_fuse(const EmCpArgs& a, int prec) {
   (void)prec;
@@ -417,7 +389,7 @@ bool em_cp_can_fuse(const EmCpArgs& a, int prec) {
 int em_cp_fused_chunks(const EmCpArgs& a, int prec) {
   const bool wj = a.walk != 2;
   int jchunks; int64_t jlen;
-  em_chunking(cdiv(a.Ipad, (int64_t)kEmThreads * em_vec(a, prec, true)), wj ? a.J : a.K, wj ? a.K : a.J, true, &jchunks, &jlen);
+  em_chunking(cdiv(a.Ipad, (int64_t)kEmThreads * em_vec(a, prec)), wj ? a.J : a.K, wj ? a.K : a.J, true, &jchunks, &jlen);
   return jchunks;
 }
 
@@ -452,15 +424,14 @@ void em_cp_pass(const EmCpArgs& a, int prec, double* ws, double* out4, hipStream
   AO_REQUIRE((wj ? a.K : a.J) <= 65535, "em_cp_pass: mode too long for one launch");   // grid.y = the fixed index
   AO_REQUIRE(!fuse || em_cp_can_fuse(a, prec), "em_cp_pass: this block cannot take the fused contraction");
   AO_REQUIRE(wj || a.C != nullptr, "em_cp_pass: a matrix block has no third mode to walk");
-  const int vec = em_vec(a, prec, fuse);
+  const int vec = em_vec(a, prec);
   const int64_t strips = cdiv(a.Ipad, (int64_t)kEmThreads * vec);
   int jchunks; int64_t jlen;
   em_chunking(strips, wj ? a.J : a.K, wj ? a.K : a.J, fuse, &jchunks, &jlen);
   const dim3 grid((unsigned)(strips * jchunks), (unsigned)(wj ? a.K : a.J));
   AO_REQUIRE((size_t)grid.x * grid.y * 4 * sizeof(double) <= em_cp_ws_bytes(a.Ipad, a.J, a.K), "em_cp_pass: workspace");
   if (prec == AOADMM_PREC_F32) {
-    if (fuse && vec == 2) em_cp_launch<float, 2, true>(a, jchunks, jlen, ws, grid, s);
-    else if (fuse) em_cp_launch<float, 4, true>(a, jchunks, jlen, ws, grid, s);
+    if (fuse) em_cp_launch<float, 4, true>(a, jchunks, jlen, ws, grid, s);
     else if (em_wide(a)) em_cp_launch<float, 4, false>(a, jchunks, jlen, ws, grid, s);
     else em_cp_k<float, 64><<<grid, kEmThreads, 0, s>>>(a, jchunks, jlen, ws);
   } else {
