@@ -389,6 +389,8 @@ def main():
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': launches,
                          'algorithmic_bytes_per_launch': bytes_per_launch,
+                         'timed_launches': 'every 4th pass of the timed region is bracketed by HIP events on the library\'s stream '
+                                           '(AOADMM_PASS_EVENT_EVERY=1: every pass); avg_launch_ms is their mean',
                          'note': 'per rank; algorithmic bytes = local tensor block read once (s_X per entry) + T written once '
                                  '(s_X*R per unfolding row); traffic = FETCH_SIZE x2 + WRITE_SIZE of a separate rocprofv3 --pmc '
                                  'run (%s)' % (os.path.relpath(pmc, ROOT) if pmc else 'none for this workload')},

@@ -1001,7 +1001,12 @@ void Engine::timed_contract(const void* X, int prec, const ContractPlan& pl, con
   KernelStats& ks = kstats_[pl.lead ? 1 : 0];
   hipEvent_t e0 = nullptr, e1 = nullptr;
   static const bool no_events = getenv("AOADMM_NO_PASS_EVENTS") != nullptr;   // development switch (tools/gap_analysis.py)
-  if (profile_ && !no_events) {
+  // Every 4th pass is bracketed by events (the three kinds of pass alternate with period 3, so the sample cycles through
+  // them): the records cost ~4 us of launch gap on each side of a pass -- nothing at 2000^3, 1 % of an iteration at one
+  // rank's share of 8 GPUs.  kernel_stats() returns the mean of the timed launches times the launch count.
+  // AOADMM_PASS_EVENT_EVERY=1 times every pass (the profile tools).
+  static const int every = [] { const char* e = getenv("AOADMM_PASS_EVENT_EVERY"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+  if (profile_ && !no_events && ks.launches % every == 0) {
     if (ks.pending.size() >= 512) fold_finished(ks);     // a long solve never holds more than a few hundred events
     if (ks.pending.size() < 4096) {
       e0 = take_event();
