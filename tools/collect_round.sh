@@ -42,7 +42,7 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 find $OUT/pp -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_prox_kernel_stats.csv
 rm -rf $OUT/pp
 for f in 0.2 0.01; do
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pe -- python3 $R/tools/time_em.py $f > $OUT/${TAG}_em_timing_$f.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pe -- python3 $R/tools/time_em.py $f 2> /dev/null | grep "mask=" > $OUT/${TAG}_em_timing_$f.txt
 find $OUT/pe -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_em_kernel_stats_$f.csv
 rm -rf $OUT/pe
 done
