@@ -55,6 +55,9 @@ struct CpBlock {
   int64_t full0 = 0;       // global size of the first mode
   int64_t row0 = 0;        // first local row of the first mode
   bool has_data = false;
+  // The natural-layout array is only read to build the three pass copies, for ||X||^2, the EM pass and the fallbacks; once
+  // all three copies exist (and no mask does) it can go: 4 -> 3 resident copies (Engine::maybe_release_natural)
+  bool x_released = false;
   // dimension-tree cache: T = X x_c F_c, valid while factor c keeps `cached_version`
   int cached_mode = -1;
   uint64_t cached_version = 0;
@@ -237,6 +240,7 @@ class Engine {
   void adopt_ksharded_xp(CpBlock& b, const void* slab, int64_t k0, int64_t kloc);
   bool want_ksharded_xp(const CpBlock& b, int64_t K, int64_t* k0, int64_t* kloc) const;
   void drop_permuted_copies(CpBlock& b);
+  void maybe_release_natural(TensorInfo& t);
   bool prefetch_next_contraction(const aoadmm_options& opt);   // true: a tensor pass was enqueued
   // `collective` = false: the block holds the whole tensor and the result is complete on this engine (op-level
   // entry on an engine that happens to belong to a communicator)

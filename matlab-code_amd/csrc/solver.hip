@@ -554,6 +554,7 @@ void Engine::block_upload(CpBlock& b, int nd, const int64_t* dims, const double*
     AO_HIP(hipStreamSynchronize(stream_));
   }
   b.has_data = true;
+  b.x_released = false;
   b.cached_mode = -1;
   b.has_xp = false; b.xp_refused = false; b.has_xq = false; b.xq_refused = false; b.has_xc = false; b.xc_refused = false;
   b.xp_ksharded = false;
@@ -641,6 +642,7 @@ double Engine::tensor_normsq(int p) {
     if (t.par2) {   // sum_k ||X_k||_F^2  (cmtf_AOADMM.m:145-155)
       tensor_sumsq(slot, t.p2.X.p, AOADMM_PREC_F64, (int64_t)t.p2.I * t.p2.Jtot, ws.d(), stream_);
     } else {
+      AO_REQUIRE(!t.blk.x_released, "internal: ||X||^2 of tensor %d asked for after its natural-layout array was released", p);
       tensor_sumsq(slot, t.blk.X.data.p, t.blk.X.prec, t.blk.X.elems_padded(), ws.d(), stream_);
       allreduce(slot, 1);
     }
@@ -692,6 +694,7 @@ void Engine::tensor_synth(int p, int rank, uint64_t seed, double noise, int prec
   synth_write(b.X.data.p, prec, A.d(), B.d(), C.d(), a, sigma, 1.0 / std::sqrt(nsq), stream_);
   AO_HIP(hipStreamSynchronize(stream_));
   b.has_data = true;
+  b.x_released = false;
   b.cached_mode = -1;
   b.has_xp = false; b.xp_refused = false; b.has_xq = false; b.xq_refused = false; b.has_xc = false; b.xc_refused = false;
   b.xp_ksharded = false;
@@ -723,6 +726,7 @@ void Engine::tensor_mask_upload(int p, const uint8_t* mask) {
   TensorInfo& t = tensors_[p];
   CpBlock& b = t.blk;
   AO_REQUIRE(b.has_data, "upload Z.object{%d} before Z.miss{%d}", p + 1, p + 1);
+  AO_REQUIRE(!b.x_released, "Z.object{%d} was released after its pass copies were built: upload it again before Z.miss{%d}", p + 1, p + 1);
   AO_HIP(hipSetDevice(device_));
   const int64_t Iloc = b.dims[0], Ip = b.X.pad0, Ifull = b.full0;
   int64_t ncols = 1;
@@ -1151,6 +1155,27 @@ bool Engine::ensure_blocked_copy(CpBlock& b) {
   b.has_xc = true;
   return true;
 }
+// Releases Z.object{p} in its natural layout once every tensor pass has its own resident copy.  A 2000^3 double array is
+// 64 GB: with the natural array and three copies a MATLAB caller sat at 256 of 288 GB before any workspace.  Policy:
+// AOADMM_RELEASE_NATURAL=1 always, =0 never, default: when less HBM is free than the array itself occupies.  Afterwards
+// Z.miss cannot be attached without uploading the data again, and aoadmm_resident_unfold_gram answers
+// AOADMM_ERR_UNSUPPORTED (the caller falls back to the host-array form).
+void Engine::maybe_release_natural(TensorInfo& t) {
+  CpBlock& b = t.blk;
+  if (b.x_released || b.nd != 3 || !(b.has_xc && b.has_xp && b.has_xq) || b.has_mask || !t.normsq_valid || !b.X.data.p) return;
+  const char* pe = getenv("AOADMM_RELEASE_NATURAL");   // read per solve (the test suite switches it inside one process)
+  const int policy = pe ? (atoi(pe) != 0 ? 1 : -1) : 0;
+  if (policy < 0) return;
+  if (policy == 0) {
+    size_t free_b = 0, total_b = 0;
+    const size_t mine = (size_t)b.X.elems_padded() * b.X.elem_size();
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b >= mine) return;
+  }
+  AO_HIP(hipStreamSynchronize(stream_));             // the copies were built from it on this stream
+  b.X.data.release();
+  b.x_released = true;
+}
+
 void Engine::drop_permuted_copies(CpBlock& b) {
   if (b.has_xp) { b.Xp.release(); b.has_xp = false; b.xp_ksharded = false; b.cached_mode = -1; }
   if (b.has_xq) { b.Xq.release(); b.has_xq = false; b.cached_mode = -1; }
@@ -1161,6 +1186,7 @@ void Engine::ensure_contraction(CpBlock& b, int pos, const FactorRef* facs, int 
                                 const int* update_seq, int nseq) {
   const int prec = b.X.prec;
   const int64_t I = b.dims[0], Ip = b.X.pad0, J = b.dims[1], K = b.dims[2];
+  if (b.x_released) use_cache = true;                  // only the pass copies are resident (maybe_release_natural)
   const bool hit = use_cache && b.cached_mode >= 0 && b.cached_mode != pos &&
                    facs[b.cached_mode].version == b.cached_version;
   if (hit) return;
@@ -3173,6 +3199,9 @@ void Engine::solve(const aoadmm_options& opt, aoadmm_result* out) {
   bool stop = false;
   while (iter <= opt.MaxOuterIters && !stop) {                                 // :87
     for (ModeInfo& mq : modes_) mq.quad.dirty = true;   // rho moves once per outer iteration ('quadratic regularization', non-symmetric L)
+    if (iter == 3)                                      // by now every pass of the schedule has run once: all copies exist
+      for (int p = 0; p < n_tensors_; ++p)
+        if (!tensors_[p].par2) maybe_release_natural(tensors_[p]);
     for (int cid = -1; cid < n_couplings_; ++cid) {                            // :89 (0 = uncoupled first)
       std::vector<int> cm;
       for (int m = 0; m < n_modes_; ++m)
@@ -3306,6 +3335,8 @@ void Engine::resident_unfold_gram(int p, int pos, int slab, double* out_host) {
     AO_REQUIRE((b.nd == 2 || b.nd == 3) && pos >= 0 && pos < b.nd, "unfold_gram handles matrices and 3-way tensors");
     if (sharded() && pos == 0)
       throw Error(AOADMM_ERR_UNSUPPORTED, "resident unfold_gram: the first mode of a row-sharded block pairs rows of different ranks");
+    if (b.x_released)
+      throw Error(AOADMM_ERR_UNSUPPORTED, "resident unfold_gram: the natural-layout array was released (only the pass copies are resident)");
     const int64_t I = b.dims[0], Ip = b.X.pad0, J = b.dims[1], K = b.nd == 3 ? b.dims[2] : 1;
     prec = b.X.prec;
     a.X = b.X.data.p;

@@ -105,6 +105,49 @@ def test_quadratic_nonsymmetric_larger_matrix(eng):
         assert rel_fro(got, ref) < 1e-10, rel_fro(got, ref)
 
 
+def test_natural_copy_released_after_the_pass_copies(pkg, monkeypatch):
+    """Engine::maybe_release_natural: once the three pass copies exist the natural-layout array is freed (by default only when
+    HBM is tight: a 2000^3 double tensor; forced here).  The solve is unchanged (1e-8 vs the oracle, and bit-identical to the
+    run that keeps the array), a second solve on the same context works, HBM use drops by one copy of the tensor, the
+    resident unfold-Gram entry answers 'unsupported' (the Python layer falls back to the host array) and Z.miss can no longer
+    be attached without uploading the data again."""
+    import ctypes as C
+    capi = __import__('importlib').import_module('matlab-code_amd._capi')
+    rng = np.random.default_rng(77)
+    dims = (120, 90, 80)                               # 864 000 entries: beyond the one-launch MTTKRP of tiny blocks
+    Z, io, _ = cp_model(dims, 4, rng, [('non-negativity',), ('TV regularization', 0.01), None])
+    G = OA.init_coupled_AOADMM_CMTF({**Z, 'prox_operators': None}, io, rng=np.random.default_rng(5))
+    opt = options(MaxOuterIters=6)
+    _, Fo, _, oo = OA.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G))
+    monkeypatch.setenv('AOADMM_RELEASE_NATURAL', '0')
+    with pkg.Engine(0) as e:
+        _, Fk, _, ok_ = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=e)
+        Y = e.resident_unfold_gram(0, 1, dims[1])
+    monkeypatch.setenv('AOADMM_RELEASE_NATURAL', '1')
+    with pkg.Engine(0) as e:
+        _, Fg, _, og = pkg.cmtf_AOADMM(Z, alg_options=opt, init=copy.deepcopy(G), engine=e)
+        for a, b, c in zip(Fo['fac'], Fg['fac'], Fk['fac']):
+            assert rel_fro(b, a) < 1e-8
+            assert np.array_equal(b, c)
+        with pytest.raises(capi.UnsupportedOnDevice):
+            e.resident_unfold_gram(0, 1, dims[1])
+        # the Python layer falls back to the host-array form
+        Z2 = dict(Z); Z2['_ranks'] = [4] * 3
+        assert e._resident_model is not None
+        from importlib import import_module
+        drv = import_module('matlab-code_amd.driver')
+        Y2 = drv.cmtf_nvecs(e._resident_model, 1, 4, e)
+        assert Y2.shape == (dims[1], 4)
+        mk = np.ones(dims, dtype=np.uint8, order='F')
+        st = e.lib.aoadmm_tensor_mask_upload(e.h, 0, mk.ctypes.data_as(C.POINTER(C.c_uint8)))
+        assert st == capi.ERR_INVALID and 'released' in e.lib.aoadmm_last_error().decode()
+        # a second solve on the same context (only the pass copies are resident)
+        pkg.upload_state(e, e._resident_model, copy.deepcopy(G))
+        out2 = pkg.run_solver(e, opt, 3)
+        assert np.allclose(out2['func_val_conv'], oo['func_val_conv'], rtol=1e-7)
+    assert Y.shape == (dims[1], dims[1])
+
+
 def test_cp_mixed_constraints_and_ls(pkg, eng):
     rng = np.random.default_rng(3)
     Z, io, _ = cp_model((30, 25, 20), 4, rng, [None, ('l2-ball', 1.0), ('unimodality', True)])
