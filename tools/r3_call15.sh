@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 3: TV kernel with the row solve -- quick check + timeline at one rank's share of 8
+set -u
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/r03_c15
+mkdir -p $OUT
+cd $R
+timeout -k 10 600 python -m pytest tests/test_gpu_solver.py tests/test_known_answers.py -m gpu -x -q > $OUT/tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -3 $OUT/tests.log
+[ $rc -eq 0 ] || exit 1
+for rep in 1 2; do
+  timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --as-rank 0 --of 8 > $OUT/rank0_of_8_$rep.json 2> /dev/null || exit 1
+  python3 -c "import json;d=json.loads(open('$OUT/rank0_of_8_$rep.json').read().strip().splitlines()[-1]);print($rep, 'of 8: ms_per_step', round(d['ms_per_step'],4), 'small', round(d['tail_breakdown']['replicated_small_kernels_ms'],4), 'passes', round(d['tail_breakdown']['tensor_passes_ms'],4))"
+done
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 10 --warmup 2 --as-rank 0 --of 8 > $OUT/rank0_of_8_under_rocprof.json 2> /dev/null
+f=$(find $OUT/prof -name "*kernel_trace.csv" | head -1); python3 $R/tools/iteration_sequence.py $f 6 9 > $OUT/iteration_sequence.txt; sed -n 5,22p $OUT/iteration_sequence.txt | cut -c1-80; tail -1 $OUT/iteration_sequence.txt
+rm -rf $OUT/prof
