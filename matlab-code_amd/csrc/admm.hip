@@ -748,7 +748,7 @@ __global__ void prox_tv_k(ColArgs a, int use_lds, const AdmmCtl* ctl) {
 // The fixed point satisfies the KKT system, i.e. is the unique minimiser; if the iteration cap is hit
 // thread 0 falls back to the sequential scan, so the result is exact either way.  Inside the ADMM loop
 // J is warm-started from the previous Z column, which usually converges in 1-3 rounds.
-static constexpr int kTvParMax = 4096;
+static constexpr int kTvParMax = 6400;       // rows of a column whose working arrays fit LDS (25 bytes per row, below)
 
 // The iteration is built on prefix sums so that no step is sequential in a
 // segment's length: with Pc[i] = sum_{t<i} (y_t - c) (c = mean(y), which keeps the prefix sums small) the value
@@ -780,7 +780,11 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
   CTL_GUARD(ctl);
   constexpr int NW = kTvThreads / 64;
   constexpr bool GLOBAL = MEM != 0;                                // columns beyond the LDS-resident 4096 rows
-  constexpr unsigned long long kIdxMask = GLOBAL ? 0xffffffull : 0xfffull;
+  // split key: magnitude bits of the worst |u| above, entry index below.  LDS-resident columns: 32 bits (float
+  // magnitude, 13-bit index -- the key only ranks violations, any violating entry is a valid split point); workspace
+  // forms: 64 bits with a 24-bit index
+  typedef typename std::conditional<GLOBAL, unsigned long long, unsigned>::type KeyT;
+  constexpr KeyT kIdxMask = GLOBAL ? (KeyT)0xffffffull : (KeyT)0x1fffu;
   extern __shared__ double lds_dyn[];
   __shared__ int wsum[NW];
   __shared__ double dsum[NW];
@@ -792,34 +796,45 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
   double* z = a.Z + a.ldz * r;
   const double lam = a.p0 / (a.rho[0] * a.rho_mul);
   // working arrays: y (n), Pc (n + 1), val (n), best (n), start (n + 1 ints), J (n bytes) -- 37 bytes per row.
-  //   MEM 0: all in LDS (<= 4096 rows)
+  //   MEM 0: all in LDS (<= 6400 rows) at 25 bytes per row: the input is staged in the slots of Pc (the prefix sums
+  //          replace it in place, every thread its own chunk; the dual update takes the input from registers and the
+  //          sequential fallback reads it from global memory again) and the split keys are 32 bits wide.  Round 3: the
+  //          limit was 4096 rows at 37 bytes, and 6000 rows ran the hybrid form at 51 us per in-loop call.
   //   MEM 2: the arrays every phase of a round walks (Pc, start, J: 13 bytes per row) in LDS, y / val / best in the
   //          column's slice of the prox workspace (<= kTvHybridMax rows; round 2 had all six in the workspace there and
   //          every phase was a chain of L2 round trips: 90 us per in-loop call at 6000 rows against 22 us at 2000)
   //   MEM 1: all in the workspace (L2-resident)
   double* gws = GLOBAL ? a.ws + (size_t)blockIdx.x * tv_ws_doubles(a.rows) : nullptr;
   double *y, *Pc, *val;
-  unsigned long long* best;
+  KeyT* best;
   int* start;
   signed char* J;
   if constexpr (MEM == 2) {
-    y = gws; val = gws + n; best = reinterpret_cast<unsigned long long*>(gws + 2 * n);
+    y = gws; val = gws + n; best = reinterpret_cast<KeyT*>(gws + 2 * n);
     Pc = lds_dyn;                                                  // n + 1
     start = reinterpret_cast<int*>(lds_dyn + n + 1);               // n + 1
     J = reinterpret_cast<signed char*>(start + n + 1);             // n
+  } else if constexpr (MEM == 0) {
+    Pc = lds_dyn;                                                  // n + 1
+    y = Pc;                                                        // the input, until the prefix sums take its place
+    val = lds_dyn + n + 1;                                         // n
+    best = reinterpret_cast<KeyT*>(val + n);                       // n (32-bit keys)
+    start = reinterpret_cast<int*>(best + n);                      // n + 1
+    J = reinterpret_cast<signed char*>(start + n + 1);             // n
   } else {
-    double* dyn = GLOBAL ? gws : lds_dyn;
+    double* dyn = gws;
     y = dyn;                                                       // n
     Pc = dyn + n;                                                  // n + 1
     val = dyn + 2 * n + 1;                                         // n
-    best = reinterpret_cast<unsigned long long*>(dyn + 3 * n + 1); // n
+    best = reinterpret_cast<KeyT*>(dyn + 3 * n + 1);               // n
     start = reinterpret_cast<int*>(dyn + 4 * n + 1);               // n + 1
     J = reinterpret_cast<signed char*>(start + n + 1);             // n
   }
   const int chunk = (n + kTvThreads - 1) / kTvThreads;
   const int c0 = min(n, t * chunk), c1 = min(n, c0 + chunk);
-  constexpr int kKeep = GLOBAL ? 1 : kTvParMax / kTvThreads;      // entries per thread of an LDS-resident column (<= 4096 rows)
+  constexpr int kKeep = GLOBAL ? 1 : 8;                            // entries per thread of an LDS-resident column (launcher: rows <= 8 * threads)
   double keep_mu[kKeep], keep_z[kKeep];                            // old mu / old Z of the entries t + k*kTvThreads (fz only)
+  double keep_y[kKeep];                                            // MEM 0: the input of the same entries (its LDS slots become Pc)
   // ---- load (coalesced, all loads of a thread independent: a chunk-ordered loop would serialise 8-16 memory
   // round trips), mean, centred prefix sums.  The warm-start column is staged in `val` the same way.
   {
@@ -840,7 +855,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
         const int i = min(t + k * kTvThreads, n - 1);
         ry[k] = vin[i];
         rw[k] = wv[i];
-        if (k < kKeep) { keep_mu[k] = mv[i]; keep_z[k] = zv[i]; }
+        if (k < kKeep) { keep_mu[k] = mv[i]; keep_z[k] = zv[i]; keep_y[k] = ry[k]; }
       }
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
@@ -866,8 +881,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
     } else if (n <= kTvThreads) stage(std::integral_constant<int, 1>());
     else if (n <= 2 * kTvThreads) stage(std::integral_constant<int, 2>());
     else if (n <= 4 * kTvThreads) stage(std::integral_constant<int, 4>());
-    else if (n <= 8 * kTvThreads) stage(std::integral_constant<int, 8>());
-    else stage(std::integral_constant<int, kTvParMax / kTvThreads>());
+    else stage(std::integral_constant<int, 8>());
   }
   __syncthreads();
   double loc = 0.0;
@@ -895,7 +909,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
     for (int i = c0; i < c1; ++i) val[i] = y[i];
   } else {
     double run = before - c * (double)c0;
-    for (int i = c0; i < c1; ++i) { Pc[i] = run; run += y[i] - c; }
+    for (int i = c0; i < c1; ++i) { const double yi = y[i]; Pc[i] = run; run += yi - c; }   // (MEM 0: y[i] IS Pc[i])
     if (c1 == n && c0 < n) Pc[n] = run;                            // the thread holding the last entry
     // ---- warm start of the jump set
     if (warm) {
@@ -939,7 +953,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
         const double sl = sa == 0 ? 0.0 : (double)J[sa - 1];
         const double sr = sb == n - 1 ? 0.0 : (double)J[sb];
         val[sgi] = c + (Pc[sb + 1] - Pc[sa] + lam * (sr - sl)) / (double)(sb - sa + 1);
-        best[sgi] = 0ull;
+        best[sgi] = (KeyT)0;
       }
       __syncthreads();
       // 3. merge jumps whose sign disagrees with the values on both sides
@@ -964,15 +978,17 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
           const double u = u0 + (Pc[i + 1] - Pc[sa]) - (val[sgi] - c) * (double)(i - sa + 1);
           const double au = fabs(u);
           if (au > thr) {
-            const unsigned long long key = ((unsigned long long)__double_as_longlong(au) & ~kIdxMask) | (unsigned long long)i;
+            KeyT key;
+            if constexpr (GLOBAL) key = ((KeyT)__double_as_longlong(au) & ~kIdxMask) | (KeyT)i;
+            else key = ((KeyT)__float_as_uint((float)au) & ~kIdxMask) | (KeyT)i;       // au > thr >= 1e-13: never a zero key
             atomicMax(&best[sgi], key);
           }
         }
       }
       __syncthreads();
       for (int sgi = t; sgi < nseg; sgi += kTvThreads) {
-        const unsigned long long b = best[sgi];
-        if (b != 0ull) {
+        const KeyT b = best[sgi];
+        if (b != (KeyT)0) {
           const int i = (int)(b & kIdxMask);
           const int sa = start[sgi];
           const double u0 = sa == 0 ? 0.0 : -lam * (double)J[sa - 1];
@@ -1007,7 +1023,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
       sol = Pc;
     } else {
       __syncthreads();
-      if (t == 0) tv1d_condat_dev(y, val, n, lam);                 // exact sequential fallback
+      if (t == 0) tv1d_condat_dev(MEM == 0 ? vin : y, val, n, lam);   // exact sequential fallback (MEM 0: the LDS copy of the input is gone)
     }
   }
   __syncthreads();
@@ -1025,7 +1041,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
     for (int k = 0; k < KP; ++k) {
       const int i = t + k * kTvThreads;
       if (i < n) {
-        const double zn = sol[i], vv = y[i];
+        const double zn = sol[i], vv = MEM == 0 ? keep_y[k < kKeep ? k : 0] : y[i];
         const double mo = keep_mu[k < kKeep ? k : 0], zo = keep_z[k < kKeep ? k : 0];   // fetched with the column
         const double x = vv - mo;                      // fac = V - mu_old
         const double mn = vv - zn;                     // mu + fac - Z   (:1428)
@@ -1062,8 +1078,7 @@ __global__ __launch_bounds__(kTvThreads) void prox_tv_fast_k(ColArgs a, const do
   } else if (n <= kTvThreads) dual(std::integral_constant<int, 1>());
   else if (n <= 2 * kTvThreads) dual(std::integral_constant<int, 2>());
   else if (n <= 4 * kTvThreads) dual(std::integral_constant<int, 4>());
-  else if (n <= 8 * kTvThreads) dual(std::integral_constant<int, 8>());
-  else dual(std::integral_constant<int, kTvParMax / kTvThreads>());
+  else dual(std::integral_constant<int, 8>());
   // the four residual sums of the column in one reduction (one barrier instead of eight)
   __shared__ double q4sum[NW][4];
   double q4[4] = {s1, s2, s3, s4};
@@ -1338,7 +1353,9 @@ size_t prox_ws_bytes(int type, int64_t rows, int R) {
 // Pc, start and J of a column in LDS (13 bytes per row): up to 12 000 rows beside the kernel's static LDS
 static constexpr int64_t kTvHybridMax = 12000;
 static size_t tv_hybrid_lds(int64_t rows) { return (size_t)(rows + 1) * 8 + (size_t)(rows + 2) * 4 + (size_t)rows + 64; }
-static size_t tv_fast_lds(int64_t rows) { return (size_t)(4 * rows + 2) * 8 + (size_t)(rows + 2) * 4 + (size_t)rows + 64; }
+static size_t tv_fast_lds(int64_t rows) {            // Pc + val doubles, 32-bit keys, start, J
+  return (size_t)(2 * rows + 1) * 8 + (size_t)rows * 4 + (size_t)(rows + 2) * 4 + (size_t)rows + 64;
+}
 static void tv_fast_launch(const ColArgs& a, const double* warm, int64_t ldw, const TvFused& fz, const AdmmCtl* ctl,
                            hipStream_t s) {
   if (a.rows > kTvParMax) {

@@ -77,10 +77,11 @@ def test_prox_matches_oracle(eng, c, shape):
 
 
 @pytest.mark.parametrize('kind', ['noise', 'steps', 'constant', 'ramp', 'strong'])
-@pytest.mark.parametrize('rows', [4097, 9000, 20011])
+@pytest.mark.parametrize('rows', [4097, 6400, 6401, 9000, 20011])
 def test_tv_prox_long_columns(eng, kind, rows):
-    """TV beyond the LDS-resident 4096 rows: the same parallel split/merge active set with its working arrays in the
-    prox workspace (prox_tv_fast_k<1024, true>) instead of the one-thread scan; exact, like the short-column kernel."""
+    """TV on long columns: up to 6400 rows all working arrays in LDS (eight entries per thread), 6401-12000 rows the
+    hybrid form (Pc / start / J in LDS, the rest in the prox workspace), beyond that everything in the workspace -- the
+    same parallel split/merge active set instead of the one-thread scan; exact, like the short-column kernel."""
     rng = np.random.default_rng(rows + zlib.crc32(kind.encode()) % 1000)
     R = 3
     if kind == 'noise':

@@ -59,11 +59,12 @@ def test_cp_tv_nonneg(pkg, eng):
     compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=15)))
 
 
-def test_cp_tv_long_mode(pkg, eng):
-    """TV on a mode longer than the LDS-resident 4096 rows: the in-loop kernel (prox + dual update + residual sums,
-    warm-started from the previous Z) with its working arrays in the prox workspace."""
+@pytest.mark.parametrize('rows', [4500, 7000])
+def test_cp_tv_long_mode(pkg, eng, rows):
+    """TV on a long mode inside the ADMM loop (prox + dual update + residual sums, warm-started from the previous Z):
+    4500 rows with eight entries per thread in LDS, 7000 rows with part of the working arrays in the prox workspace."""
     rng = np.random.default_rng(12)
-    Z, io, _ = cp_model((4500, 9, 8), 3, rng, [('TV regularization', 0.01), ('non-negativity',), ('non-negativity',)])
+    Z, io, _ = cp_model((rows, 9, 8), 3, rng, [('TV regularization', 0.01), ('non-negativity',), ('non-negativity',)])
     compare(*run_both(pkg, eng, Z, io, options(MaxOuterIters=6)))
 
 
