@@ -172,12 +172,17 @@ def main():
         env.setdefault('OMP_NUM_THREADS', '4')
         raise SystemExit(subprocess.call(plan['cmd'], env=env))
     rank, world, local_rank = plan['rank'], plan['world'], plan['local_rank']
+    # before anything touches the GPU: RCCL between processes needs dmabuf IPC on this driver (hipIpcGetMemHandle fails
+    # otherwise); the launcher normally exports it already
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='gloo', rank=rank, world_size=world)   # control plane only
+        # control plane only; a rank that dies early must not leave the others waiting for the default half hour
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
     torch.cuda.set_device(local_rank)
 
     pkg = importlib.import_module('matlab-code_amd')
